@@ -1,0 +1,264 @@
+"""Qubit staging: choose which k qubits are shard-local, stage by stage.
+
+Behavioural mirror of the reference planner wenbo_engine/circuit/staging.py
+(Atlas-style staging, Xu et al. SC'24): `atlas_stages(cd, k, method)` returns
+`(steps, log_to_phys)` with the same step lists as the reference for the
+"heuristic" and "greedy" methods (pinned by tests/golden/planner.json).
+
+On the MI355X build the step list *is* the multi-GPU schedule:
+
+  * k = number of local qubits of one GPU shard (n - log2(#GPUs));
+  * `{"local_ops": [...]}` steps run as local HIP kernels, no communication;
+  * SWAP entries in `nonlocal_ops`, `([p_out < k, p_in >= k], SWAP)`, are the
+    re-layout requests: consecutive SWAPs of one step are merged by the
+    distributed runner into ONE all-to-all over xGMI;
+  * gates left in `nonlocal_ops` because only their *insular* (diagonal) qubits
+    are global need no exchange on the GPU (rank-bit phase) -- the reference
+    executes them as butterflies (staging.py:67-72), this build does not.
+
+`method="ilp"` needs PuLP, which this image does not have; it raises ImportError
+exactly like the reference does without PuLP (staging.py:203-204).
+"""
+from __future__ import annotations
+
+from collections import Counter
+
+import numpy as np
+
+from quantum_simulations_amd.circuit.fusion import batch_levels, fuse_1q_ops
+from quantum_simulations_amd.circuit.io import levelize, validate_circuit_dict
+from quantum_simulations_amd.kernel import gates as gate_table
+
+try:  # optional, reference staging.py:49-53
+    import pulp  # type: ignore  # noqa: F401
+    HAS_PULP = True
+except ImportError:
+    HAS_PULP = False
+
+# Diagonal ("sparse") gates: none of their qubits has to be local (Atlas is_sparse()).
+_DIAGONAL_GATES = frozenset({"Z", "S", "T", "CZ", "CR"})
+
+
+def non_insular_qubits(gate: dict) -> list[int]:
+    """Qubits of `gate` that must sit in the local set for it to run in a stage."""
+    return [] if gate["gate"] in _DIAGONAL_GATES else list(gate["qubits"])
+
+
+class QubitMap:
+    """Logical <-> physical qubit positions (physical = bit of the stored index)."""
+
+    def __init__(self, n: int):
+        self.n = n
+        self._phys_of = list(range(n))
+        self._logical_at = list(range(n))
+
+    def phys(self, logical: int) -> int:
+        return self._phys_of[logical]
+
+    def logical(self, physical: int) -> int:
+        return self._logical_at[physical]
+
+    def local_set(self, k: int) -> set[int]:
+        return set(self._logical_at[: min(k, self.n)])
+
+    def swap_phys(self, pa: int, pb: int) -> None:
+        qa, qb = self._logical_at[pa], self._logical_at[pb]
+        self._logical_at[pa], self._logical_at[pb] = qb, qa
+        self._phys_of[qa], self._phys_of[qb] = pb, pa
+
+    def to_list(self) -> list[int]:
+        return list(self._phys_of)
+
+    def is_identity(self) -> bool:
+        return self._phys_of == list(range(self.n))
+
+
+# ------------------------------------------------------------------ shared pieces
+def _relayout_ops(qmap: QubitMap, have: set[int], want: set[int]) -> list[tuple]:
+    """SWAP ops ([p_out, p_in], SWAP) moving `want - have` in and `have - want` out,
+    paired in ascending logical order; updates `qmap`."""
+    swap_u = gate_table.SWAP()
+    ops = []
+    for q_in, q_out in zip(sorted(want - have), sorted(have - want)):
+        p_in, p_out = qmap.phys(q_in), qmap.phys(q_out)
+        ops.append(([p_out, p_in], swap_u))
+        qmap.swap_phys(p_out, p_in)
+    return ops
+
+
+def _as_physical_op(gate: dict, qmap: QubitMap) -> tuple:
+    return ([qmap.phys(q) for q in gate["qubits"]],
+            gate_table.gate_matrix(gate["gate"], gate["params"]))
+
+
+def _fused_local_step(gates: list[dict], qmap: QubitMap) -> list[dict]:
+    if not gates:
+        return []
+    return [{"local_ops": fuse_1q_ops([_as_physical_op(g, qmap) for g in gates]),
+             "nonlocal_ops": []}]
+
+
+# ------------------------------------------------------------- heuristic (Atlas)
+def _sweep_executable(gates, done, is_local, on_run=None) -> bool:
+    """One in-order sweep: run every not-yet-done gate whose qubits are unblocked and
+    whose non-insular qubits are local; a gate that cannot run blocks its qubits.
+    Returns True when everything is done."""
+    blocked: set[int] = set()
+    finished = True
+    for gi, gate in enumerate(gates):
+        if done[gi]:
+            continue
+        qs = gate["qubits"]
+        if blocked.isdisjoint(qs) and all(is_local[q] for q in non_insular_qubits(gate)):
+            done[gi] = True
+            if on_run is not None:
+                on_run(gate)
+        else:
+            finished = False
+            blocked.update(qs)
+    return finished
+
+
+def _compute_local_qubits_heuristic(gates: list[dict], n: int, k: int) -> list[set[int]]:
+    """Dependency-aware greedy from Atlas (`num_iterations_by_heuristics`): when the
+    sweep stalls, rank qubits by (in first stalled gate, #stalled gates needing a
+    re-layout, #stalled gates already local, index) and take the top k."""
+    if not gates:
+        return [set(range(min(k, n)))]
+    done = [False] * len(gates)
+    is_local = [False] * n
+    stages: list[set[int]] = []
+    while not _sweep_executable(gates, done, is_local):
+        in_first = [False] * n
+        need_move = [0] * n
+        already_ok = [0] * n
+        seen_first = False
+        for gi, gate in enumerate(gates):
+            if done[gi]:
+                continue
+            runnable_here = all(is_local[q] for q in non_insular_qubits(gate))
+            for q in gate["qubits"]:
+                if runnable_here:
+                    already_ok[q] += 1
+                else:
+                    need_move[q] += 1
+                if not seen_first:
+                    in_first[q] = True
+            seen_first = True
+        ranked = sorted(range(n), key=lambda q: (not in_first[q], -need_move[q],
+                                                 -already_ok[q], q))
+        chosen = set(ranked[:k])
+        stages.append(chosen)
+        is_local = [q in chosen for q in range(n)]
+    return stages
+
+
+def _local_sets_to_steps(gates, n: int, k: int, local_sets) -> tuple[list[dict], list[int]]:
+    """Stage sets -> steps: [SWAP step] [fused local step] [insular-global step] per stage."""
+    qmap = QubitMap(n)
+    steps: list[dict] = []
+    done = [False] * len(gates)
+    for want in local_sets:
+        relayout = _relayout_ops(qmap, qmap.local_set(k), want)
+        if relayout:
+            steps.append({"local_ops": [], "nonlocal_ops": relayout})
+        is_local = [q in want for q in range(n)]
+        stage_local: list[dict] = []
+        stage_global: list[tuple] = []
+
+        def place(gate: dict) -> None:
+            if all(qmap.phys(q) < k for q in gate["qubits"]):
+                stage_local.append(gate)
+            else:  # only insular qubits are global
+                stage_global.append(_as_physical_op(gate, qmap))
+
+        _sweep_executable(gates, done, is_local, on_run=place)
+        steps.extend(_fused_local_step(stage_local, qmap))
+        if stage_global:
+            steps.append({"local_ops": [], "nonlocal_ops": stage_global})
+    return steps, qmap.to_list()
+
+
+# --------------------------------------------------------------- greedy (legacy)
+def _greedy_stages(gates: list[dict], n: int, k: int, lookahead: int):
+    """Gate-by-gate: on the first non-local gate, re-layout to the k most frequent
+    qubits of the next `lookahead` gates (ties by first appearance, then pad by index)."""
+    qmap = QubitMap(n)
+    steps: list[dict] = []
+    run: list[dict] = []
+    for gi, gate in enumerate(gates):
+        if all(qmap.phys(q) < k for q in gate["qubits"]):
+            run.append(gate)
+            continue
+        steps.extend(_fused_local_step(run, qmap))
+        run = []
+        freq: Counter = Counter()
+        for later in gates[gi:gi + lookahead]:
+            for q in later["qubits"]:
+                freq[q] += 1
+        want: set[int] = set()
+        for q, _ in freq.most_common():
+            want.add(q)
+            if len(want) >= k:
+                break
+        for q in range(n):
+            if len(want) >= k:
+                break
+            want.add(q)
+        relayout = _relayout_ops(qmap, qmap.local_set(k), want)
+        if relayout:
+            steps.append({"local_ops": [], "nonlocal_ops": relayout})
+        if all(qmap.phys(q) < k for q in gate["qubits"]):
+            run.append(gate)
+        else:
+            steps.append({"local_ops": [], "nonlocal_ops": [_as_physical_op(gate, qmap)]})
+    steps.extend(_fused_local_step(run, qmap))
+    return steps, qmap.to_list()
+
+
+# ------------------------------------------------------------------- entry points
+def atlas_stages(circuit_dict: dict, k: int, method: str = "heuristic",
+                 lookahead: int = 200) -> tuple[list[dict], list[int]]:
+    """Circuit -> (steps, log_to_phys).  `k` = log2(shard amplitudes)."""
+    cd = validate_circuit_dict(circuit_dict)
+    n = cd["number_of_qubits"]
+    gates = cd["gates"]
+    if n <= k:  # everything fits one shard
+        return batch_levels(levelize(cd), k), list(range(n))
+    if method == "greedy":
+        return _greedy_stages(gates, n, k, lookahead)
+    if method == "ilp":
+        if not HAS_PULP:
+            raise ImportError("PuLP is required for method='ilp'. pip install pulp")
+        raise NotImplementedError("ILP staging is out of scope of the MI355X build "
+                                  "(SURVEY 2 row 2); use 'heuristic' or 'greedy'")
+    if method != "heuristic":
+        raise ValueError(f"unknown staging method: {method!r}")
+    return _local_sets_to_steps(gates, n, k, _compute_local_qubits_heuristic(gates, n, k))
+
+
+def permute_state(state: np.ndarray, log_to_phys: list[int]) -> np.ndarray:
+    """Physical-layout vector -> logical order (host utility for downloaded states;
+    reference staging.py:639-658).  Axis j of the C-ordered [2]*n view is bit n-1-j."""
+    n = len(log_to_phys)
+    if all(p == q for q, p in enumerate(log_to_phys)):
+        return state
+    axes = [0] * n
+    for q, p in enumerate(log_to_phys):
+        axes[n - 1 - q] = n - 1 - p
+    return np.ascontiguousarray(state.reshape((2,) * n).transpose(axes)).reshape(-1)
+
+
+def staging_stats(circuit_dict: dict, k: int, method: str = "heuristic") -> dict:
+    """Step counts with and without staging (reference staging.py:663-689)."""
+    cd = validate_circuit_dict(circuit_dict)
+    plain = batch_levels(levelize(cd), k)
+    staged, _ = atlas_stages(circuit_dict, k, method=method)
+    saved = (1 - len(staged) / max(len(plain), 1)) * 100
+    return {
+        "baseline_steps": len(plain),
+        "staged_steps": len(staged),
+        "baseline_nonlocal_steps": sum(1 for s in plain if s.get("nonlocal_ops")),
+        "staged_nonlocal_steps": sum(1 for s in staged if s.get("nonlocal_ops")),
+        "reduction": f"{len(plain)}->{len(staged)} ({saved:.0f}% fewer I/O passes)",
+    }

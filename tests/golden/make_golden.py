@@ -1,0 +1,393 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures by RUNNING THE REFERENCE in the build container.
+
+    cd /root/repo && PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Imports `wenbo_engine.*` and `v1_implementation.src.*` from /root/reference
+(read-only; never copied), feeds them seeded inputs and stores inputs + outputs as
+small data files next to this script.  The reference does not exist on the GPU
+box: tests only ever read the files written here.
+
+Fixture groups:
+  G1 gate_matrices.npz   gate_matrix() for all 15 gates / parameter samples
+  G2 states.npz + circuits.json   ref_dense.simulate() final states and the
+                         reference generators' circuit dicts
+  G3 kernels.npz         cpu_scalar/cpu_batched apply_1q/apply_2q and the four
+                         cpu_nonlocal butterflies on seeded random chunks
+  G4 planner.json        levelize / fuse_1q_ops / batch_levels / atlas_stages /
+                         permute_state / non_insular_qubits outputs
+  G5 v1_sql.npz          v1 SQL engine final states (== G2) + row counts
+  G6 chunked_c64.npz     single_node.run(chunk_size=2|4) complex64 results
+"""
+from __future__ import annotations
+
+import json
+import sqlite3
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+REF = Path("/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, str(REF))
+sys.path.insert(0, str(REF / "v1_implementation"))
+sys.path.insert(0, str(REPO))
+
+from wenbo_engine.circuit import fusion as ref_fusion  # noqa: E402
+from wenbo_engine.circuit import io as ref_io  # noqa: E402
+from wenbo_engine.circuit import staging as ref_staging  # noqa: E402
+from wenbo_engine.kernel import cpu_batched, cpu_nonlocal, cpu_scalar  # noqa: E402
+from wenbo_engine.kernel import gates as ref_gates  # noqa: E402
+from wenbo_engine.kernel import ref_dense  # noqa: E402
+from wenbo_engine.runner import single_node as ref_runner  # noqa: E402
+from wenbo_engine.tests.fixtures import circuits as ref_fixtures  # noqa: E402
+
+from src import circuits as v1_circuits  # noqa: E402  (v1_implementation/src)
+from src import db as v1_db  # noqa: E402
+from src import simulator as v1_sim  # noqa: E402
+
+# this build's own seeded workload generators (circuit JSON is stored with the state)
+from quantum_simulations_amd import circuits as own_circuits  # noqa: E402
+
+
+# ------------------------------------------------------------------ serialisation
+def cplx_list(a) -> list:
+    a = np.asarray(a, dtype=np.complex128)
+    return [[float(z.real), float(z.imag)] for z in a.reshape(-1)]
+
+
+def circuit_to_json(cd: dict) -> dict:
+    gates = []
+    for g in cd["gates"]:
+        e = {"qubits": list(g["qubits"]), "gate": g["gate"]}
+        if g.get("params"):
+            p = {}
+            for k, v in g["params"].items():
+                if isinstance(v, np.ndarray):
+                    p[k] = {"__c128__": cplx_list(v), "shape": list(v.shape)}
+                elif isinstance(v, (np.integer,)):
+                    p[k] = int(v)
+                elif isinstance(v, (np.floating,)):
+                    p[k] = float(v)
+                else:
+                    p[k] = v
+            e["params"] = p
+        gates.append(e)
+    return {"number_of_qubits": cd["number_of_qubits"], "gates": gates}
+
+
+def ops_to_json(ops) -> list:
+    return [{"qubits": list(qs), "U": cplx_list(U), "dim": int(U.shape[0])} for qs, U in ops]
+
+
+def steps_to_json(steps) -> list:
+    out = []
+    for s in steps:
+        e = {"local_ops": ops_to_json(s["local_ops"]),
+             "nonlocal_ops": ops_to_json(s["nonlocal_ops"])}
+        if "level_indices" in s:
+            e["level_indices"] = list(s["level_indices"])
+        out.append(e)
+    return out
+
+
+# ------------------------------------------------------------------------------ G1
+def make_gate_matrices():
+    out = {}
+    for name in ("H", "X", "Y", "Z", "S", "T", "CNOT", "SWAP", "CZ", "CY"):
+        out[name] = ref_gates.gate_matrix(name, {})
+    for tag, theta in (("pi3", np.pi / 3), ("pi4", np.pi / 4), ("1p234", 1.234)):
+        out[f"RY|theta={tag}"] = ref_gates.gate_matrix("RY", {"theta": theta})
+    for k in range(1, 7):
+        out[f"R|k={k}"] = ref_gates.gate_matrix("R", {"k": k})
+        out[f"CR|k={k}"] = ref_gates.gate_matrix("CR", {"k": k})
+    for p in (2, 3, 5):
+        out[f"G|p={p}"] = ref_gates.gate_matrix("G", {"p": p})
+    for e in (1, 2, 4):
+        out[f"CU|U=Z|e={e}"] = ref_gates.gate_matrix("CU", {"U": ref_gates.Z(), "exponent": e})
+    out["CU|U=G3|e=1"] = ref_gates.gate_matrix("CU", {"U": ref_gates.G(3), "exponent": 1})
+    np.savez(HERE / "gate_matrices.npz", **out)
+    return len(out)
+
+
+# ------------------------------------------------------------------------------ G2
+def make_states():
+    circuits = {
+        "bell_2q": ref_fixtures.bell_2q(),
+        "x_on_q0_3q": ref_fixtures.x_on_q0_3q(),
+        "ry_theta": ref_fixtures.ry_theta(),
+        "cr3_encoded": ref_fixtures.cr3_encoded(),
+    }
+    for n in range(2, 13):
+        circuits[f"fx_ghz_{n}"] = ref_fixtures.ghz(n)
+    for n in range(2, 11):
+        circuits[f"fx_qft_{n}"] = ref_fixtures.qft(n)
+    for n in (3, 6, 10):
+        circuits[f"v1_ghz_qft_{n}"] = v1_circuits.generate_ghz_qft(n)
+    for n in (2, 3, 5, 7):
+        circuits[f"v1_qpe_{n}"] = v1_circuits.generate_qpe_circuit(n)
+    for n in (3, 4, 6, 8):
+        circuits[f"v1_w_{n}"] = v1_circuits.generate_w_circuit(n)
+        circuits[f"v1_w_qft_{n}"] = v1_circuits.generate_w_qft(n)
+    for n in (4, 10):
+        circuits[f"v1_hadamard_wall_{n}"] = v1_circuits.generate_hadamard_wall(n)
+    circuits["v1_ghz_8"] = v1_circuits.generate_ghz_circuit(8)
+    circuits["v1_ghz_8_rev"] = v1_circuits.generate_ghz_circuit(8, reverse=True)
+    circuits["v1_qft_8"] = v1_circuits.generate_qft_circuit(8)
+    circuits["v1_qft_5_rev"] = v1_circuits.generate_qft_circuit(5, reverse=True)
+    circuits["v1_ghz_proned_6_17"] = v1_circuits.generate_ghz_proned(6, 17)
+    # this build's seeded workloads (configs 2 and 4 at oracle-sized n)
+    circuits["own_random_1q_cx_10"] = own_circuits.random_1q_cx_circuit(10, depth=40)
+    circuits["own_random_1q_cx_7"] = own_circuits.random_1q_cx_circuit(7, depth=12, seed=7)
+    circuits["own_clifford_t_10"] = own_circuits.random_clifford_t_circuit(10, depth=60)
+
+    states = {name: ref_dense.simulate(cd) for name, cd in circuits.items()}
+    np.savez_compressed(HERE / "states.npz", **states)
+    with open(HERE / "circuits.json", "w") as f:
+        json.dump({k: circuit_to_json(v) for k, v in circuits.items()}, f)
+    return len(states)
+
+
+# ------------------------------------------------------------------------------ G3
+def random_unitary(rng, dim):
+    z = rng.standard_normal((dim, dim)) + 1j * rng.standard_normal((dim, dim))
+    q, r = np.linalg.qr(z)
+    return q * (np.diag(r) / np.abs(np.diag(r)))
+
+
+def make_kernels():
+    rng = np.random.default_rng(8086)
+    K = 8
+    N = 1 << K
+    chunk = (rng.standard_normal(N) + 1j * rng.standard_normal(N)).astype(np.complex128)
+    chunk /= np.linalg.norm(chunk)
+    out = {"chunk_in": chunk}
+    mats = {}
+
+    g1 = {"H": ref_gates.H(), "T": ref_gates.T(), "RY": ref_gates.RY(1.234),
+          "G3": ref_gates.G(3), "U1": random_unitary(rng, 2)}
+    for name, U in g1.items():
+        mats[f"m1_{name}"] = U
+        for q in range(K):
+            a = chunk.copy()
+            cpu_scalar.apply_1q(a, q, U)
+            b = chunk.copy()
+            cpu_batched.apply_1q(b, q, U)
+            assert np.allclose(a, b, atol=1e-15)
+            out[f"k1|{name}|q={q}"] = a
+
+    g2 = {"CNOT": ref_gates.CNOT(), "CZ": ref_gates.CZ(), "CY": ref_gates.CY(),
+          "SWAP": ref_gates.SWAP(), "CR3": ref_gates.CR(3),
+          "CUG3": ref_gates.CU(ref_gates.G(3), 1), "U2": random_unitary(rng, 4)}
+    pairs = [(0, 1), (1, 0), (0, 7), (7, 2), (3, 5), (6, 7), (7, 6), (5, 6)]
+    for name, U in g2.items():
+        mats[f"m2_{name}"] = U
+        for qa, qb in pairs:
+            a = chunk.copy()
+            cpu_scalar.apply_2q(a, qa, qb, U)
+            out[f"k2|{name}|qa={qa}|qb={qb}"] = a
+
+    # partner-chunk butterflies on 4 chunks of 2^6
+    M = 1 << 6
+    quad = [(rng.standard_normal(M) + 1j * rng.standard_normal(M)).astype(np.complex128)
+            for _ in range(4)]
+    for i, c in enumerate(quad):
+        out[f"nl_in_{i}"] = c
+    for name in ("H", "U1"):
+        c0, c1 = quad[0].copy(), quad[1].copy()
+        cpu_nonlocal.apply_1q_pair(c0, c1, g1[name])
+        out[f"nl|1q_pair|{name}|c0"], out[f"nl|1q_pair|{name}|c1"] = c0, c1
+    for name in ("CNOT", "CUG3", "U2", "SWAP", "CR3"):
+        U = g2[name]
+        for q in (0, 3, 5):
+            c0, c1 = quad[0].copy(), quad[1].copy()
+            cpu_nonlocal.apply_2q_pair_qa_local(c0, c1, q, U)
+            out[f"nl|qa_local|{name}|q={q}|c0"], out[f"nl|qa_local|{name}|q={q}|c1"] = c0, c1
+            c0, c1 = quad[0].copy(), quad[1].copy()
+            cpu_nonlocal.apply_2q_pair_qb_local(c0, c1, q, U)
+            out[f"nl|qb_local|{name}|q={q}|c0"], out[f"nl|qb_local|{name}|q={q}|c1"] = c0, c1
+        cs = [c.copy() for c in quad]
+        cpu_nonlocal.apply_2q_quad(*cs, U)
+        for i, c in enumerate(cs):
+            out[f"nl|quad|{name}|c{i}"] = c
+    out.update(mats)
+    np.savez(HERE / "kernels.npz", **out)
+    return len(out)
+
+
+# ------------------------------------------------------------------------------ G4
+def staging_test_circuits():
+    c4 = {"number_of_qubits": 4, "gates": [
+        {"qubits": [0], "gate": "H"}, {"qubits": [2], "gate": "H"},
+        {"qubits": [0, 2], "gate": "CNOT"}, {"qubits": [1, 3], "gate": "CNOT"}]}
+    c5 = {"number_of_qubits": 5, "gates": [
+        {"qubits": [0], "gate": "H"}, {"qubits": [1], "gate": "H"}, {"qubits": [2], "gate": "H"},
+        {"qubits": [3], "gate": "X"}, {"qubits": [4], "gate": "Y"},
+        {"qubits": [0, 3], "gate": "CNOT"}, {"qubits": [1, 4], "gate": "CZ"},
+        {"qubits": [2, 3], "gate": "SWAP"}]}
+    c4b = {"number_of_qubits": 4, "gates": [
+        {"qubits": [q], "gate": "H"} for q in range(4)] + [
+        {"qubits": [0, 2], "gate": "CNOT"}, {"qubits": [1, 3], "gate": "CNOT"},
+        {"qubits": [0, 3], "gate": "CZ"}]}
+    c8 = {"number_of_qubits": 8, "gates": [
+        {"qubits": [4], "gate": "H"}, {"qubits": [5], "gate": "H"}, {"qubits": [6], "gate": "H"},
+        {"qubits": [4, 5], "gate": "CNOT"}, {"qubits": [5, 6], "gate": "CNOT"},
+        {"qubits": [4, 6], "gate": "CZ"}, {"qubits": [4], "gate": "T"}, {"qubits": [5], "gate": "S"},
+        {"qubits": [4, 5], "gate": "CNOT"}, {"qubits": [5, 6], "gate": "CNOT"},
+        {"qubits": [0], "gate": "H"}, {"qubits": [1], "gate": "H"}, {"qubits": [2], "gate": "H"},
+        {"qubits": [0, 1], "gate": "CNOT"}, {"qubits": [1, 2], "gate": "CNOT"},
+        {"qubits": [0, 2], "gate": "CZ"}]}
+    call = {"number_of_qubits": 4, "gates": [{"qubits": [0], "gate": "H"},
+                                             {"qubits": [1], "gate": "X"}]}
+    return {"stg_4q": (c4, [2]), "stg_5q": (c5, [2, 3]), "stg_4q_b": (c4b, [2]),
+            "stg_8q": (c8, [3, 4]), "stg_all_local": (call, [2])}
+
+
+def make_planner():
+    doc = {"levelize": {}, "batch_levels": {}, "atlas": {}, "fuse": [], "permute": [],
+           "insular": [], "circuits": {}}
+    circuits = {name: (cd, ks) for name, (cd, ks) in staging_test_circuits().items()}
+    for n in (6, 7, 8):
+        circuits[f"qft_{n}"] = (ref_fixtures.qft(n), [2, 3, 4])
+    circuits["ghz_6"] = (ref_fixtures.ghz(6), [2, 3])
+    circuits["rand_9"] = (own_circuits.random_1q_cx_circuit(9, depth=10, seed=99), [3, 5])
+    circuits["clifft_9"] = (own_circuits.random_clifford_t_circuit(9, depth=12, seed=5), [4, 6])
+    circuits["w_qft_6"] = (v1_circuits.generate_w_qft(6), [3])
+
+    for name, (cd, ks) in circuits.items():
+        doc["circuits"][name] = circuit_to_json(cd)
+        vcd = ref_io.validate_circuit_dict(cd)
+        levels = ref_io.levelize(vcd)
+        # level membership as indices into the validated gate list
+        ids = {id(g): i for i, g in enumerate(vcd["gates"])}
+        doc["levelize"][name] = [[ids[id(g)] for g in lv] for lv in levels]
+        for k in ks:
+            doc["batch_levels"][f"{name}|k={k}"] = steps_to_json(ref_fusion.batch_levels(levels, k))
+            for method in ("heuristic", "greedy"):
+                steps, l2p = ref_staging.atlas_stages(cd, k, method=method)
+                doc["atlas"][f"{name}|k={k}|{method}"] = {
+                    "steps": steps_to_json(steps), "log_to_phys": list(l2p)}
+
+    H, T, S, CX = ref_gates.H(), ref_gates.T(), ref_gates.S(), ref_gates.CNOT()
+    fuse_cases = [
+        [([0], H), ([0], T)],
+        [([0], H), ([0, 1], CX), ([0], T)],
+        [([0], H), ([1], ref_gates.X())],
+        [([0], H), ([0], T), ([0], S)],
+        [([2], H), ([1], T), ([1, 2], CX), ([2], S), ([0], H), ([1], H), ([0, 1], CX), ([0], T)],
+    ]
+    for ops in fuse_cases:
+        doc["fuse"].append({"in": ops_to_json(ops), "out": ops_to_json(ref_fusion.fuse_1q_ops(ops))})
+
+    rng = np.random.default_rng(5)
+    for l2p in ([0, 1], [1, 0], [2, 0, 1], [3, 1, 0, 2], [4, 2, 0, 1, 3]):
+        n = len(l2p)
+        st = (rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n))
+        doc["permute"].append({"log_to_phys": l2p, "in": cplx_list(st),
+                               "out": cplx_list(ref_staging.permute_state(st, l2p))})
+
+    for gate in ({"gate": "Z", "qubits": [3], "params": {}}, {"gate": "S", "qubits": [0], "params": {}},
+                 {"gate": "T", "qubits": [2], "params": {}}, {"gate": "CZ", "qubits": [0, 3], "params": {}},
+                 {"gate": "CR", "qubits": [1, 4], "params": {"k": 2}},
+                 {"gate": "H", "qubits": [0], "params": {}}, {"gate": "CNOT", "qubits": [0, 1], "params": {}},
+                 {"gate": "SWAP", "qubits": [2, 5], "params": {}}, {"gate": "CY", "qubits": [1, 0], "params": {}},
+                 {"gate": "RY", "qubits": [1], "params": {"theta": 0.3}}):
+        doc["insular"].append({"gate": gate, "out": ref_staging.non_insular_qubits(gate)})
+
+    with open(HERE / "planner.json", "w") as f:
+        json.dump(doc, f)
+    return len(doc["atlas"])
+
+
+# ------------------------------------------------------------------------------ G5
+def run_v1(cd):
+    con = sqlite3.connect(":memory:")
+    v1_db.initialize_schema(con, REF / "v1_implementation" / "sql" / "schema.sql")
+    with tempfile.TemporaryDirectory() as td:
+        version = v1_sim.run_circuit(con, cd, checkpoint_dir=td)
+    n = cd["number_of_qubits"]
+    psi = np.zeros(1 << n, dtype=np.complex128)
+    for idx, re, im in con.execute(
+            "SELECT idx, real, imag FROM state WHERE version = ?", (version,)):
+        psi[idx] = complex(re, im)
+    counts = [c for (c,) in con.execute(
+        "SELECT COUNT(*) FROM state GROUP BY version ORDER BY version")]
+    con.close()
+    return psi, counts
+
+
+def make_v1():
+    out = {}
+    cases = {
+        "ghz_3": v1_circuits.generate_ghz_circuit(3), "ghz_8": v1_circuits.generate_ghz_circuit(8),
+        "qft_4": v1_circuits.generate_qft_circuit(4), "qft_8": v1_circuits.generate_qft_circuit(8),
+        "w_4": v1_circuits.generate_w_circuit(4), "w_8": v1_circuits.generate_w_circuit(8),
+        "qpe_5": v1_circuits.generate_qpe_circuit(5),
+        "ghz_qft_6": v1_circuits.generate_ghz_qft(6),
+        "w_qft_6": v1_circuits.generate_w_qft(6),
+    }
+    circ_json = {}
+    for name, cd in cases.items():
+        psi, counts = run_v1(cd)
+        ref = ref_dense.simulate(cd)
+        assert np.max(np.abs(psi - ref)) < 1e-14, name
+        out[f"{name}|state"] = psi
+        out[f"{name}|rows"] = np.array(counts, dtype=np.int64)
+        circ_json[name] = circuit_to_json(cd)
+    np.savez_compressed(HERE / "v1_sql.npz", **out)
+    with open(HERE / "v1_sql_circuits.json", "w") as f:
+        json.dump(circ_json, f)
+    return len(cases)
+
+
+# ------------------------------------------------------------------------------ G6
+def make_chunked():
+    NQ = 4
+    cases = {
+        "h_q2": ({"number_of_qubits": NQ, "gates": [{"qubits": [2], "gate": "H"}]}, 4),
+        "x_q3": ({"number_of_qubits": NQ, "gates": [{"qubits": [3], "gate": "X"}]}, 4),
+        "cnot_q0_q2": ({"number_of_qubits": NQ, "gates": [
+            {"qubits": [0], "gate": "H"}, {"qubits": [0, 2], "gate": "CNOT"}]}, 4),
+        "cy_q2_q1": ({"number_of_qubits": NQ, "gates": [
+            {"qubits": [2], "gate": "H"}, {"qubits": [2, 1], "gate": "CY"}]}, 4),
+        "cz_q3_q2": ({"number_of_qubits": NQ, "gates": [
+            {"qubits": [2], "gate": "H"}, {"qubits": [3], "gate": "H"},
+            {"qubits": [3, 2], "gate": "CZ"}]}, 4),
+        "h_all": ({"number_of_qubits": NQ, "gates": [
+            {"qubits": [i], "gate": "H"} for i in range(NQ)]}, 4),
+        "ghz4_cs2": (ref_fixtures.ghz(4), 2),
+        "ghz6_cs4": (ref_fixtures.ghz(6), 4),
+        "qft4_cs4": (ref_fixtures.qft(4), 4),
+        "qft4_cs2": (ref_fixtures.qft(4), 2),
+        "qft6_cs8_fused": (ref_fixtures.qft(6), 8),
+        "qft6_cs8_staged": (ref_fixtures.qft(6), 8),
+    }
+    out, circ_json = {}, {}
+    for name, (cd, cs) in cases.items():
+        kw = {}
+        if name.endswith("_fused"):
+            kw["use_fusion"] = True
+        if name.endswith("_staged"):
+            kw["use_staging"] = True
+        with tempfile.TemporaryDirectory() as td:
+            final = ref_runner.run(cd, td, chunk_size=cs, use_wal=False, **kw)
+            got = ref_runner.collect_state(final, apply_permutation=True, work_dir=td)
+        out[name] = got
+        circ_json[name] = {"circuit": circuit_to_json(cd), "chunk_size": cs, "kwargs": kw}
+    np.savez_compressed(HERE / "chunked_c64.npz", **out)
+    with open(HERE / "chunked_c64.json", "w") as f:
+        json.dump(circ_json, f)
+    return len(cases)
+
+
+if __name__ == "__main__":
+    print("G1 gate matrices:", make_gate_matrices())
+    print("G2 states:", make_states())
+    print("G3 kernel cases:", make_kernels())
+    print("G4 planner cases:", make_planner())
+    print("G5 v1 SQL cases:", make_v1())
+    print("G6 chunked cases:", make_chunked())

@@ -1,0 +1,188 @@
+"""Host-side planner/front-end parity: this build's io/fusion/staging/circuits reproduce the
+reference's outputs (tests/golden/planner.json, circuits.json) and its contract tests
+(wenbo_engine/tests/test_contract.py, test_fusion.py, test_staging.py restated)."""
+import numpy as np
+import pytest
+
+from quantum_simulations_amd import circuits as gen
+from quantum_simulations_amd.circuit import fusion, staging
+from quantum_simulations_amd.circuit.io import ENDIANNESS, levelize, validate_circuit_dict
+from quantum_simulations_amd.kernel import gates as gt
+from tests.golden_io import c128, circuit_from_json, golden_circuits, jdoc, npz, ops_from_json
+
+PLAN = jdoc("planner.json")
+
+
+def _same_ops(got, want_json, tol=0.0):
+    want = ops_from_json(want_json)
+    assert [list(q) for q, _ in got] == [q for q, _ in want]
+    for (_, Ug), (_, Uw) in zip(got, want):
+        assert Ug.shape == Uw.shape
+        if tol:
+            np.testing.assert_allclose(Ug, Uw, rtol=0, atol=tol)
+        else:
+            np.testing.assert_array_equal(Ug, Uw)
+
+
+def _same_steps(got, want):
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        _same_ops(g["local_ops"], w["local_ops"])
+        _same_ops(g["nonlocal_ops"], w["nonlocal_ops"])
+        if "level_indices" in w:
+            assert g["level_indices"] == w["level_indices"]
+
+
+# ------------------------------------------------------------------ gate table (G1)
+def _gate_case(key):
+    parts = key.split("|")
+    name, params = parts[0], {}
+    for kv in parts[1:]:
+        k, v = kv.split("=")
+        if k == "theta":
+            params[k] = {"pi3": np.pi / 3, "pi4": np.pi / 4, "1p234": 1.234}[v]
+        elif k == "U":
+            params[k] = {"Z": gt.Z(), "G3": gt.G(3)}[v]
+        elif k == "e":
+            params["exponent"] = int(v)
+        else:
+            params[k] = int(v)
+    return name, params
+
+
+@pytest.mark.parametrize("key", sorted(npz("gate_matrices.npz")))
+def test_gate_table_bit_exact(key):
+    name, params = _gate_case(key)
+    np.testing.assert_array_equal(gt.gate_matrix(name, params), npz("gate_matrices.npz")[key])
+    assert gt.is_2q(name) == (npz("gate_matrices.npz")[key].shape == (4, 4))
+
+
+def test_unknown_gate():
+    with pytest.raises(ValueError, match="unknown gate"):
+        gt.gate_matrix("FOO", {})
+    assert not gt.is_2q("FOO")
+
+
+# ------------------------------------------------------------------ generators
+def _strip(cd):
+    out = []
+    for g in validate_circuit_dict(cd)["gates"]:
+        p = {k: (np.asarray(v).tolist() if isinstance(v, np.ndarray) else v)
+             for k, v in g["params"].items()}
+        out.append((g["gate"], g["qubits"], p))
+    return cd["number_of_qubits"], out
+
+
+@pytest.mark.parametrize("name,build", [
+    ("v1_ghz_8", lambda: gen.generate_ghz_circuit(8)),
+    ("v1_ghz_8_rev", lambda: gen.generate_ghz_circuit(8, reverse=True)),
+    ("v1_qft_8", lambda: gen.generate_qft_circuit(8)),
+    ("v1_qft_5_rev", lambda: gen.generate_qft_circuit(5, reverse=True)),
+    ("v1_qpe_5", lambda: gen.generate_qpe_circuit(5)),
+    ("v1_w_6", lambda: gen.generate_w_circuit(6)),
+    ("v1_w_qft_8", lambda: gen.generate_w_qft(8)),
+    ("v1_ghz_qft_10", lambda: gen.generate_ghz_qft(10)),
+    ("v1_hadamard_wall_10", lambda: gen.generate_hadamard_wall(10)),
+    ("v1_ghz_proned_6_17", lambda: gen.generate_ghz_proned(6, 17)),
+    ("fx_ghz_5", lambda: gen.generate_ghz_circuit(5)),
+    ("fx_qft_7", lambda: gen.generate_qft_circuit(7)),
+    ("own_random_1q_cx_10", lambda: gen.random_1q_cx_circuit(10, depth=40)),
+    ("own_clifford_t_10", lambda: gen.random_clifford_t_circuit(10, depth=60)),
+])
+def test_generators_emit_reference_dicts(name, build):
+    assert _strip(build()) == _strip(golden_circuits()[name])
+
+
+# ------------------------------------------------------------------ contract (io.py)
+def test_contract_normalisation():
+    assert ENDIANNESS == "little"
+    d = validate_circuit_dict(golden_circuits()["cr3_encoded"])
+    assert d["gates"][2] == {"qubits": [0, 1], "gate": "CR", "params": {"k": 3}}
+    d = validate_circuit_dict({"number_of_qubits": 2, "gates": [{"qubits": [1], "gate": "R4"}]})
+    assert d["gates"][0]["gate"] == "R" and d["gates"][0]["params"] == {"k": 4}
+    d = validate_circuit_dict({"number_of_qubits": 2, "gates": [
+        {"qubits": [0, 1], "gate": "CR3", "params": {"k": 5}}]})
+    assert d["gates"][0]["params"]["k"] == 5  # explicit params override the name
+
+
+@pytest.mark.parametrize("bad,msg", [
+    ({"gates": []}, "missing required keys"),
+    ({"number_of_qubits": 2, "gates": [{"qubits": [0], "gate": "FOOBAR"}]}, "unsupported gate"),
+    ({"number_of_qubits": 2, "gates": [{"qubits": [0, 1], "gate": "H"}]}, "needs 1"),
+    ({"number_of_qubits": 2, "gates": [{"qubits": [0], "gate": "CNOT"}]}, "needs 2"),
+    ({"number_of_qubits": 2, "gates": [{"qubits": [5], "gate": "X"}]}, "out of range"),
+    ({"number_of_qubits": 2, "gates": [], "extra": True}, "unknown top-level"),
+    ({"number_of_qubits": 2, "gates": [{"qubits": [0], "gate": "RY"}]}, "requires param"),
+    ({"number_of_qubits": 2, "gates": [{"qubits": [0], "gate": "H", "foo": 1}]}, "unknown keys"),
+    ({"number_of_qubits": 0, "gates": []}, "positive int"),
+    ({"number_of_qubits": 2, "gates": {}}, "must be a list"),
+    ({"number_of_qubits": 2, "gates": [{"qubits": [0.5], "gate": "H"}]}, r"list\[int\]"),
+    ({"number_of_qubits": 2, "gates": [{"gate": "H"}]}, "missing 'qubits' or 'gate'"),
+    ({"number_of_qubits": 2, "gates": [{"qubits": [0], "gate": "RY",
+                                        "params": {"theta": "x"}}]}, "bad type"),
+    ([], "must be a dict"),
+])
+def test_contract_errors(bad, msg):
+    with pytest.raises(ValueError, match=msg):
+        validate_circuit_dict(bad)
+
+
+# ------------------------------------------------------------------ levelize / fusion
+@pytest.mark.parametrize("name", sorted(PLAN["levelize"]))
+def test_levelize(name):
+    cd = validate_circuit_dict(circuit_from_json(PLAN["circuits"][name]))
+    ids = {id(g): i for i, g in enumerate(cd["gates"])}
+    assert [[ids[id(g)] for g in lv] for lv in levelize(cd)] == PLAN["levelize"][name]
+
+
+def test_fuse_1q_ops_cases():
+    for case in PLAN["fuse"]:
+        _same_ops(fusion.fuse_1q_ops(ops_from_json(case["in"])), case["out"])
+    assert fusion.fuse_1q_ops([]) == []
+    H, T, S = gt.H(), gt.T(), gt.S()
+    fused = fusion.fuse_1q_ops([([0], H), ([0], T), ([0], S)])
+    np.testing.assert_allclose(fused[0][1], S @ T @ H, atol=1e-14)  # test_fusion.py:52-62
+
+
+@pytest.mark.parametrize("key", sorted(PLAN["batch_levels"]))
+def test_batch_levels(key):
+    name, k = key.split("|k=")
+    cd = validate_circuit_dict(circuit_from_json(PLAN["circuits"][name]))
+    _same_steps(fusion.batch_levels(levelize(cd), int(k)), PLAN["batch_levels"][key])
+
+
+def test_fusion_stats_keys():
+    cd = validate_circuit_dict(gen.generate_qft_circuit(4))
+    st = fusion.fusion_stats(levelize(cd), 4)
+    assert st["fused_passes"] == 1 and st["local_only_passes"] == 1
+    assert set(st) == {"original_levels", "fused_passes", "local_only_passes",
+                       "io_reduction", "ops_before", "ops_after"}
+
+
+# ------------------------------------------------------------------ staging
+@pytest.mark.parametrize("key", sorted(PLAN["atlas"]))
+def test_atlas_stages(key):
+    name, k, method = key.split("|")
+    cd = circuit_from_json(PLAN["circuits"][name])
+    steps, l2p = staging.atlas_stages(cd, int(k[2:]), method=method)
+    assert l2p == PLAN["atlas"][key]["log_to_phys"]
+    _same_steps(steps, PLAN["atlas"][key]["steps"])
+
+
+def test_staging_misc():
+    for case in PLAN["insular"]:
+        assert staging.non_insular_qubits(case["gate"]) == case["out"]
+    for case in PLAN["permute"]:
+        got = staging.permute_state(c128(case["in"]), case["log_to_phys"])
+        np.testing.assert_array_equal(got, c128(case["out"]))
+    qm = staging.QubitMap(6)
+    assert qm.local_set(3) == {0, 1, 2}
+    qm.swap_phys(1, 4)
+    assert qm.local_set(3) == {0, 4, 2} and qm.phys(4) == 1 and qm.logical(4) == 1
+    assert not qm.is_identity() and qm.to_list() == [0, 4, 2, 3, 1, 5]
+    with pytest.raises(ValueError, match="unknown staging method"):
+        staging.atlas_stages(gen.generate_qft_circuit(4), 2, method="nope")
+    with pytest.raises(ImportError):
+        staging.atlas_stages(gen.generate_qft_circuit(4), 2, method="ilp")
+    st = staging.staging_stats(gen.generate_qft_circuit(6), 3)
+    assert {"baseline_steps", "staged_steps", "reduction"} <= set(st)
