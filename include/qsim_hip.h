@@ -1,0 +1,106 @@
+/*
+ * qsim_hip.h -- C ABI of libqsim_hip.so, the MI355X (gfx950) gate-application engine.
+ *
+ * This is the drop-in boundary for the gate-application hot path of
+ * onofreiandrea/quantum_simulations.  The reference calls six free Python functions on
+ * caller-owned numpy chunks (wenbo_engine/runner/single_node.py:25-28,103-106,208-321):
+ *
+ *     cpu_scalar.apply_1q(chunk, qubit, U)              wenbo_engine/kernel/cpu_scalar.py:21
+ *     cpu_scalar.apply_2q(chunk, qa, qb, U)             wenbo_engine/kernel/cpu_scalar.py:35
+ *     cpu_nonlocal.apply_1q_pair(c0, c1, U)             wenbo_engine/kernel/cpu_nonlocal.py:22
+ *     cpu_nonlocal.apply_2q_pair_qa_local(c0,c1,qa,U)   wenbo_engine/kernel/cpu_nonlocal.py:29
+ *     cpu_nonlocal.apply_2q_pair_qb_local(c0,c1,qb,U)   wenbo_engine/kernel/cpu_nonlocal.py:45
+ *     cpu_nonlocal.apply_2q_quad(c00,c01,c10,c11,U)     wenbo_engine/kernel/cpu_nonlocal.py:61
+ *
+ * Here a "chunk" is an opaque handle to 2^k complex128 amplitudes resident in HBM
+ * (interleaved re,im doubles; amplitude i at byte offset 16*i).  Conventions are the
+ * reference's: qubit q <-> bit q of the chunk-local index (little-endian); a 2-qubit
+ * matrix is row-major 4x4, big-endian inside the pair (row/col = 2*bit(qa)+bit(qb)).
+ * Matrices are passed as interleaved (re,im) doubles: U[8] for 2x2, U[32] for 4x4.
+ *
+ * Every function returns 0 on success or a negative QSIM_ERR_* code; the message is
+ * available from qsim_last_error() (thread-local).  Nothing throws across the ABI.
+ * Calls on one handle are serialised by the caller; kernels are enqueued on the
+ * handle's stream and only qsim_sync/qsim_download/qsim_norm2/qsim_time_end block.
+ */
+#ifndef QSIM_HIP_H
+#define QSIM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QSIM_OK            0
+#define QSIM_ERR_INVALID  (-1)  /* bad argument (null handle, qa == qb, range, ...)        */
+#define QSIM_ERR_NONLOCAL (-2)  /* qubit >= log2(chunk): the reference's                    */
+                                /* NotImplementedError("... non-local ...")                 */
+#define QSIM_ERR_HIP      (-3)  /* a HIP runtime call failed                                */
+#define QSIM_ERR_NOMEM    (-4)  /* device allocation failed                                 */
+
+typedef struct qsim_chunk qsim_chunk;
+
+/* ---- library / device ------------------------------------------------------------ */
+const char* qsim_last_error(void);
+int qsim_version(void);
+int qsim_device_count(int* count);
+
+/* ---- chunk lifetime (replaces block_store.read_chunk/init_zero_state,
+ *      wenbo_engine/storage/block_store.py:31-65: chunks live in HBM, not on disk) --- */
+int qsim_create(int device, int n_local_qubits, qsim_chunk** out);
+/* A window [offset, offset + 2^n_local_qubits) of an existing chunk (chunk c of a
+ * 2^n state held in one allocation: offset = c << k, block_store.py:14-15).          */
+int qsim_create_view(qsim_chunk* parent, uint64_t offset_amps, int n_local_qubits,
+                     qsim_chunk** out);
+/* Adopt caller-owned device memory (e.g. a torch tensor used for RCCL exchange);
+ * `stream` is a hipStream_t (NULL = default stream).  Memory is never freed here.    */
+int qsim_wrap(int device, void* device_ptr, int n_local_qubits, void* stream,
+              qsim_chunk** out);
+int qsim_destroy(qsim_chunk* c);
+int qsim_n_local_qubits(const qsim_chunk* c);
+void* qsim_device_ptr(const qsim_chunk* c);
+
+/* ---- state I/O ------------------------------------------------------------------- */
+int qsim_init_zero(qsim_chunk* c, int set_amp0);          /* |0..0> when set_amp0 != 0 */
+int qsim_init_random(qsim_chunk* c, uint64_t seed);       /* normalised, counter-based  */
+int qsim_upload(qsim_chunk* c, const double* re_im, uint64_t offset_amps, uint64_t count);
+int qsim_download(qsim_chunk* c, double* re_im, uint64_t offset_amps, uint64_t count);
+int qsim_copy(qsim_chunk* dst, const qsim_chunk* src);    /* device-to-device, same k  */
+
+/* ---- local butterflies (cpu_scalar.apply_1q / apply_2q) --------------------------- */
+int qsim_apply_1q(qsim_chunk* c, int qubit, const double U[8]);
+int qsim_apply_2q(qsim_chunk* c, int qa, int qb, const double U[32]);
+/* A pass of n_ops gates in order (single_node._process_local_chunk, :208-216).
+ * nq[i] in {1,2}; qubits[2*i], qubits[2*i+1]; mats + 32*i holds U (8 or 32 doubles). */
+int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits,
+                   const double* mats);
+
+/* ---- partner-chunk butterflies (cpu_nonlocal.*) ----------------------------------- */
+int qsim_apply_1q_pair(qsim_chunk* c0, qsim_chunk* c1, const double U[8]);
+int qsim_apply_2q_pair_qa_local(qsim_chunk* c0, qsim_chunk* c1, int qa, const double U[32]);
+int qsim_apply_2q_pair_qb_local(qsim_chunk* c0, qsim_chunk* c1, int qb, const double U[32]);
+int qsim_apply_2q_quad(qsim_chunk* c00, qsim_chunk* c01, qsim_chunk* c10, qsim_chunk* c11,
+                       const double U[32]);
+
+/* ---- exchange helpers for the multi-GPU runner ------------------------------------- */
+/* dst[j] = src[i] for the 2^(k-1) amplitudes i of src with bit `bit` == value, in
+ * ascending order (pack), and the inverse scatter (unpack).  `buf` holds k-1 qubits.   */
+int qsim_pack_half(const qsim_chunk* src, int bit, int value, qsim_chunk* buf);
+int qsim_unpack_half(qsim_chunk* dst, int bit, int value, const qsim_chunk* buf);
+
+/* ---- synchronisation, reductions, timing ------------------------------------------- */
+int qsim_sync(qsim_chunk* c);
+int qsim_norm2(qsim_chunk* c, double* out);               /* sum |amp|^2               */
+/* max_i |amp_i - expected_i| for closed-form states, evaluated on the device:
+ * kind 0: GHZ (1/sqrt2 at local index 0 of the first chunk and at the last index of the
+ *         last), kind 1: GHZ+QFT  2^-(n+1)/2 (1 + exp(-2 pi i y / 2^n)), y = base + i.  */
+int qsim_max_abs_err_closed_form(qsim_chunk* c, int kind, int n_total_qubits,
+                                 uint64_t base_index, double* out);
+int qsim_time_begin(qsim_chunk* c);                        /* hipEventRecord on stream  */
+int qsim_time_end(qsim_chunk* c, float* elapsed_ms);       /* record + synchronize      */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QSIM_HIP_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of libqsim_hip.so (C ABI declared in include/qsim_hip.h).
+
+There is deliberately no fallback: if the shared library has not been built
+(`python -c "import __graft_entry__ as g; g.build()"` or `make -C
+quantum_simulations_amd/csrc`) loading raises `QsimLibraryMissing`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_NAME = "libqsim_hip.so"
+LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
+
+QSIM_OK = 0
+QSIM_ERR_INVALID = -1
+QSIM_ERR_NONLOCAL = -2
+QSIM_ERR_HIP = -3
+QSIM_ERR_NOMEM = -4
+
+
+class QsimLibraryMissing(RuntimeError):
+    pass
+
+
+class QsimHipError(RuntimeError):
+    pass
+
+
+_P = C.c_void_p
+_D = C.POINTER(C.c_double)
+_I32 = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); every symbol include/qsim_hip.h declares
+SIGNATURES = {
+    "qsim_last_error": (C.c_char_p, []),
+    "qsim_version": (C.c_int, []),
+    "qsim_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "qsim_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
+    "qsim_create_view": (C.c_int, [_P, C.c_uint64, C.c_int, C.POINTER(_P)]),
+    "qsim_wrap": (C.c_int, [C.c_int, _P, C.c_int, _P, C.POINTER(_P)]),
+    "qsim_destroy": (C.c_int, [_P]),
+    "qsim_n_local_qubits": (C.c_int, [_P]),
+    "qsim_device_ptr": (_P, [_P]),
+    "qsim_init_zero": (C.c_int, [_P, C.c_int]),
+    "qsim_init_random": (C.c_int, [_P, C.c_uint64]),
+    "qsim_upload": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
+    "qsim_download": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
+    "qsim_copy": (C.c_int, [_P, _P]),
+    "qsim_apply_1q": (C.c_int, [_P, C.c_int, _P]),
+    "qsim_apply_2q": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "qsim_apply_ops": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "qsim_apply_1q_pair": (C.c_int, [_P, _P, _P]),
+    "qsim_apply_2q_pair_qa_local": (C.c_int, [_P, _P, C.c_int, _P]),
+    "qsim_apply_2q_pair_qb_local": (C.c_int, [_P, _P, C.c_int, _P]),
+    "qsim_apply_2q_quad": (C.c_int, [_P, _P, _P, _P, _P]),
+    "qsim_pack_half": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "qsim_unpack_half": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "qsim_sync": (C.c_int, [_P]),
+    "qsim_norm2": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "qsim_max_abs_err_closed_form": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64,
+                                               C.POINTER(C.c_double)]),
+    "qsim_time_begin": (C.c_int, [_P]),
+    "qsim_time_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the library; raises if it was never built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise QsimLibraryMissing(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "This engine has no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    """Map a C return code to the exception the reference's Python API raises."""
+    if rc == QSIM_OK:
+        return
+    msg = (load().qsim_last_error() or b"").decode("utf-8", "replace")
+    if rc == QSIM_ERR_NONLOCAL:
+        raise NotImplementedError(msg)  # cpu_scalar.check_local, cpu_scalar.py:13-18
+    if rc == QSIM_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == QSIM_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise QsimHipError(msg)

@@ -1,0 +1,785 @@
+// libqsim_hip.so -- gate-application kernels for MI355X (gfx950 / CDNA4), C ABI in
+// include/qsim_hip.h.  Written for wave64, 16-byte (complex128) lane accesses and the
+// HBM roofline: every gate is a streaming read-modify-write of the amplitudes it touches.
+//
+// Kernel family (one template, `k_gate<NM, ITEMS>`):
+//   a gate is reduced on the host to
+//     * a sorted list of index bit positions that are *removed* from the work-item
+//       index (target bits and fixed-one control/diagonal bits),
+//     * NM = 1, 2 or 4 "member" base pointers (the NM amplitudes one work item owns:
+//       target-bit combinations, with fixed-one bits and partner-chunk selection folded
+//       into the pointer),
+//     * an NM x NM complex matrix.
+//   NM=1: x *= d           diagonal Z/S/T/R (half the state), CZ/CR (a quarter)
+//   NM=2: 2x2 butterfly    dense 1q, controlled-1q (CNOT/CY/CU: half), SWAP (half),
+//                          apply_1q_pair across two chunks
+//   NM=4: 4x4 butterfly    dense 2q, partner-chunk pair/quad forms
+//   Each amplitude belongs to exactly one work item, so the update is in place with
+//   no inter-thread hazard.  Lanes own consecutive work items => a wave's 16-B loads
+//   cover contiguous runs of 2^(lowest removed bit) amplitudes (1 KiB when that bit >= 6).
+//
+// Algorithmic HBM bytes per launch: 32 * NM * count (read + write of every member).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/qsim_hip.h"
+
+typedef unsigned long long u64;
+
+// ------------------------------------------------------------------ error plumbing
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                 \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      return fail(e_ == hipErrorOutOfMemory ? QSIM_ERR_NOMEM : QSIM_ERR_HIP,          \
+                  "%s failed: %s", #expr, hipGetErrorString(e_));                     \
+  } while (0)
+
+// ------------------------------------------------------------------ chunk handle
+struct qsim_chunk {
+  int device;
+  int k;                 // log2(amplitudes)
+  double2* amp;          // device pointer
+  hipStream_t stream;
+  bool owns_memory;
+  qsim_chunk* parent;    // for views (keeps nothing alive; caller orders destruction)
+  hipEvent_t ev0, ev1;   // timing
+  bool have_events;
+  double* scratch;       // reduction workspace (lazily allocated, owned)
+};
+
+static const int kMaxDevices = 16;
+static hipStream_t g_stream[kMaxDevices];
+static bool g_stream_ready[kMaxDevices];
+static std::mutex g_mu;
+
+static int device_stream(int device, hipStream_t* out) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (device < 0 || device >= kMaxDevices) return fail(QSIM_ERR_INVALID, "device %d out of range", device);
+  if (!g_stream_ready[device]) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&g_stream[device], hipStreamNonBlocking));
+    g_stream_ready[device] = true;
+  }
+  *out = g_stream[device];
+  return QSIM_OK;
+}
+
+static inline u64 amps(const qsim_chunk* c) { return 1ull << c->k; }
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cfma(double2 a, double2 b, double2 acc) {
+  // acc + a*b
+  return make_double2(fma(a.x, b.x, fma(-a.y, b.y, acc.x)), fma(a.x, b.y, fma(a.y, b.x, acc.y)));
+}
+
+// Re-insert zero bits at ascending positions pos[0..npos) of a compressed index.
+__device__ __forceinline__ u64 expand_index(u64 c, int npos, int p0, int p1, int p2) {
+  if (npos > 0) c = ((c >> p0) << (p0 + 1)) | (c & ((1ull << p0) - 1));
+  if (npos > 1) c = ((c >> p1) << (p1 + 1)) | (c & ((1ull << p1) - 1));
+  if (npos > 2) c = ((c >> p2) << (p2 + 1)) | (c & ((1ull << p2) - 1));
+  return c;
+}
+
+template <int NM>
+struct GateArgs {
+  double2* member[NM];  // base pointer of each member (offsets folded in)
+  u64 count;            // work items
+  int npos;
+  int pos[3];
+  double2 u[NM * NM];   // row-major NM x NM
+};
+
+constexpr int kBlock = 256;
+
+template <int NM, int ITEMS>
+__global__ __launch_bounds__(kBlock) void k_gate(const GateArgs<NM> a) {
+  const u64 first = ((u64)blockIdx.x * ITEMS) * kBlock + threadIdx.x;
+  u64 idx[ITEMS];
+  bool live[ITEMS];
+  double2 x[ITEMS][NM];
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    const u64 c = first + (u64)r * kBlock;
+    live[r] = c < a.count;
+    idx[r] = expand_index(c, a.npos, a.pos[0], a.pos[1], a.pos[2]);
+  }
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    if (live[r]) {
+#pragma unroll
+      for (int m = 0; m < NM; ++m) x[r][m] = a.member[m][idx[r]];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    if (live[r]) {
+#pragma unroll
+      for (int row = 0; row < NM; ++row) {
+        double2 acc = cmul(a.u[row * NM], x[r][0]);
+#pragma unroll
+        for (int col = 1; col < NM; ++col) acc = cfma(a.u[row * NM + col], x[r][col], acc);
+        a.member[row][idx[r]] = acc;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host: gate plan
+struct Group {        // 1, 2 or 4 chunks forming a virtual index space of k + g bits
+  qsim_chunk* c[4];
+  int n;              // number of chunks (1, 2, 4)
+  int k;              // local bits
+};
+
+struct Plan {
+  int nm;                   // 1, 2, 4
+  double2* member[4];
+  u64 count;
+  int npos;
+  int pos[3];
+  double2 u[16];
+};
+
+static inline bool is_zero(double re, double im) { return re == 0.0 && im == 0.0; }
+static inline bool is_one(double re, double im) { return re == 1.0 && im == 0.0; }
+
+// Resolve a virtual offset (bits >= k select the chunk) to a device pointer.
+static double2* resolve(const Group& g, u64 voff) {
+  const u64 ci = voff >> g.k;
+  return g.c[ci]->amp + (voff & ((1ull << g.k) - 1));
+}
+
+// Build a plan: `targets` (matrix order, MSB first), `fixed` one-bits, nm x nm matrix.
+static int make_plan(const Group& g, const int* targets, int nt, const int* fixed, int nf,
+                     const double* mat, Plan* p) {
+  p->nm = 1 << nt;
+  int removed[4];
+  int nr = 0;
+  for (int i = 0; i < nt; ++i) if (targets[i] < g.k) removed[nr++] = targets[i];
+  for (int i = 0; i < nf; ++i) if (fixed[i] < g.k) removed[nr++] = fixed[i];
+  if (nr > 3) return fail(QSIM_ERR_INVALID, "internal: more than 3 removed bits");
+  std::sort(removed, removed + nr);
+  p->npos = nr;
+  for (int i = 0; i < 3; ++i) p->pos[i] = i < nr ? removed[i] : 0;
+  p->count = 1ull << (g.k - nr);
+  u64 fixed_off = 0;
+  for (int i = 0; i < nf; ++i) fixed_off |= 1ull << fixed[i];
+  for (int m = 0; m < p->nm; ++m) {
+    u64 off = fixed_off;
+    for (int t = 0; t < nt; ++t)
+      if ((m >> (nt - 1 - t)) & 1) off |= 1ull << targets[t];
+    p->member[m] = resolve(g, off);
+  }
+  for (int i = 0; i < p->nm * p->nm; ++i) p->u[i] = make_double2(mat[2 * i], mat[2 * i + 1]);
+  return QSIM_OK;
+}
+
+template <int NM, int ITEMS>
+static int launch_plan_t(const Plan& p, hipStream_t stream) {
+  GateArgs<NM> a;
+  for (int m = 0; m < NM; ++m) a.member[m] = p.member[m];
+  a.count = p.count;
+  a.npos = p.npos;
+  for (int i = 0; i < 3; ++i) a.pos[i] = p.pos[i];
+  for (int i = 0; i < NM * NM; ++i) a.u[i] = p.u[i];
+  const u64 per_block = (u64)kBlock * ITEMS;
+  const u64 blocks = (p.count + per_block - 1) / per_block;
+  if (blocks > 0x7fffffffull) return fail(QSIM_ERR_INVALID, "grid too large");
+  hipLaunchKernelGGL((k_gate<NM, ITEMS>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, a);
+  HIP_TRY(hipGetLastError());
+  return QSIM_OK;
+}
+
+static int launch_plan(const Plan& p, hipStream_t stream) {
+  switch (p.nm) {
+    case 1: return launch_plan_t<1, 8>(p, stream);
+    case 2: return launch_plan_t<2, 4>(p, stream);
+    case 4: return launch_plan_t<4, 2>(p, stream);
+  }
+  return fail(QSIM_ERR_INVALID, "internal: bad member count %d", p.nm);
+}
+
+// Classify + launch a 1-qubit gate on virtual qubit `q` of the group.
+static int gate_1q(const Group& g, int q, const double* U, hipStream_t stream) {
+  Plan p;
+  int rc;
+  const bool diag = is_zero(U[2], U[3]) && is_zero(U[4], U[5]);
+  if (diag && is_one(U[0], U[1])) {
+    if (is_one(U[6], U[7])) return QSIM_OK;  // identity
+    rc = make_plan(g, nullptr, 0, &q, 1, U + 6, &p);  // scale the bit-set half by U11
+  } else {
+    rc = make_plan(g, &q, 1, nullptr, 0, U, &p);
+  }
+  if (rc) return rc;
+  return launch_plan(p, stream);
+}
+
+// Classify + launch a 2-qubit gate on virtual qubits (qa = MSB, qb = LSB).
+static int gate_2q(const Group& g, int qa, int qb, const double* U, hipStream_t stream) {
+  auto z = [&](int r, int c) { return is_zero(U[2 * (4 * r + c)], U[2 * (4 * r + c) + 1]); };
+  auto one = [&](int r, int c) { return is_one(U[2 * (4 * r + c)], U[2 * (4 * r + c) + 1]); };
+  Plan p;
+  int rc;
+  bool offdiag_zero = true;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c)
+      if (r != c && !z(r, c)) offdiag_zero = false;
+  // controlled on qa: [[I, 0], [0, V]]
+  const bool ctrl_a = one(0, 0) && one(1, 1) && z(0, 1) && z(1, 0) &&
+                      z(0, 2) && z(0, 3) && z(1, 2) && z(1, 3) &&
+                      z(2, 0) && z(2, 1) && z(3, 0) && z(3, 1);
+  // controlled on qb: identity on indices {0, 2}, V on {1, 3}
+  const bool ctrl_b = one(0, 0) && one(2, 2) && z(0, 2) && z(2, 0) &&
+                      z(0, 1) && z(0, 3) && z(2, 1) && z(2, 3) &&
+                      z(1, 0) && z(1, 2) && z(3, 0) && z(3, 2);
+  const bool swap = one(0, 0) && one(3, 3) && one(1, 2) && one(2, 1) && z(1, 1) && z(2, 2) &&
+                    z(0, 1) && z(0, 2) && z(0, 3) && z(1, 0) && z(1, 3) &&
+                    z(2, 0) && z(2, 3) && z(3, 0) && z(3, 1) && z(3, 2);
+  if (offdiag_zero && one(0, 0) && one(1, 1) && one(2, 2)) {
+    if (one(3, 3)) return QSIM_OK;  // identity
+    const int fixed[2] = {qa, qb};
+    rc = make_plan(g, nullptr, 0, fixed, 2, U + 2 * 15, &p);  // CZ / CR: quarter of the state
+  } else if (ctrl_a) {
+    const double V[8] = {U[2 * 10], U[2 * 10 + 1], U[2 * 11], U[2 * 11 + 1],
+                         U[2 * 14], U[2 * 14 + 1], U[2 * 15], U[2 * 15 + 1]};
+    rc = make_plan(g, &qb, 1, &qa, 1, V, &p);  // CNOT / CY / CU: half of the state
+  } else if (ctrl_b) {
+    const double V[8] = {U[2 * 5], U[2 * 5 + 1], U[2 * 7], U[2 * 7 + 1],
+                         U[2 * 13], U[2 * 13 + 1], U[2 * 15], U[2 * 15 + 1]};
+    rc = make_plan(g, &qa, 1, &qb, 1, V, &p);
+  } else if (swap) {
+    // exchange |01> <-> |10>: a 2-member work item whose members are (a=0,b=1), (a=1,b=0)
+    Plan q;
+    const int t[2] = {qa, qb};
+    static const double I4[32] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0,
+                                  0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0};
+    rc = make_plan(g, t, 2, nullptr, 0, I4, &q);
+    if (rc) return rc;
+    p.nm = 2;
+    p.member[0] = q.member[1];
+    p.member[1] = q.member[2];
+    p.count = q.count;
+    p.npos = q.npos;
+    for (int i = 0; i < 3; ++i) p.pos[i] = q.pos[i];
+    p.u[0] = make_double2(0, 0); p.u[1] = make_double2(1, 0);
+    p.u[2] = make_double2(1, 0); p.u[3] = make_double2(0, 0);
+    rc = QSIM_OK;
+  } else {
+    const int t[2] = {qa, qb};
+    rc = make_plan(g, t, 2, nullptr, 0, U, &p);
+  }
+  if (rc) return rc;
+  return launch_plan(p, stream);
+}
+
+// ------------------------------------------------------------------ argument checks
+static int check_chunk(const qsim_chunk* c, const char* what) {
+  if (!c || !c->amp) return fail(QSIM_ERR_INVALID, "%s: null chunk", what);
+  return QSIM_OK;
+}
+
+static int check_local_qubit(const qsim_chunk* c, int q) {
+  if (q < 0) return fail(QSIM_ERR_INVALID, "qubit %d is negative", q);
+  if (q >= c->k)
+    return fail(QSIM_ERR_NONLOCAL,
+                "qubit %d >= log2(chunk_size)=%d: non-local gate requires layout/collect step",
+                q, c->k);
+  return QSIM_OK;
+}
+
+static int check_group(qsim_chunk* const* cs, int n, const char* what) {
+  for (int i = 0; i < n; ++i) {
+    int rc = check_chunk(cs[i], what);
+    if (rc) return rc;
+    if (cs[i]->k != cs[0]->k) return fail(QSIM_ERR_INVALID, "%s: chunks differ in size", what);
+    if (cs[i]->device != cs[0]->device)
+      return fail(QSIM_ERR_INVALID, "%s: chunks live on different devices", what);
+    for (int j = 0; j < i; ++j)
+      if (cs[i]->amp == cs[j]->amp) return fail(QSIM_ERR_INVALID, "%s: the same chunk twice", what);
+  }
+  return QSIM_OK;
+}
+
+// ------------------------------------------------------------------ misc kernels
+__global__ void k_fill_zero(double2* p, u64 n, int set0) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    p[i] = make_double2((i == 0 && set0) ? 1.0 : 0.0, 0.0);
+}
+
+__device__ __forceinline__ u64 splitmix64(u64 x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// amplitude i = (u(2i), u(2i+1)), u(j) = (splitmix64(seed + j) >> 11) * 2^-52 - 1 in [-1, 1)
+__global__ void k_fill_random(double2* p, u64 n, u64 seed) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double re = (double)(splitmix64(seed + 2 * i) >> 11) * (1.0 / 4503599627370496.0) - 1.0;
+    const double im = (double)(splitmix64(seed + 2 * i + 1) >> 11) * (1.0 / 4503599627370496.0) - 1.0;
+    p[i] = make_double2(re, im);
+  }
+}
+
+__global__ void k_scale(double2* p, u64 n, double s) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double2 v = p[i];
+    p[i] = make_double2(v.x * s, v.y * s);
+  }
+}
+
+__global__ void k_copy(double2* __restrict__ dst, const double2* __restrict__ src, u64 n) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+// dst[j] = src[insert(j, bit, value)]  /  inverse
+__global__ void k_pack_half(double2* __restrict__ dst, const double2* __restrict__ src, u64 n_half,
+                            int bit, u64 value_off) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n_half; j += stride) {
+    const u64 i = (((j >> bit) << (bit + 1)) | (j & ((1ull << bit) - 1))) | value_off;
+    dst[j] = src[i];
+  }
+}
+__global__ void k_unpack_half(double2* __restrict__ dst, const double2* __restrict__ src, u64 n_half,
+                              int bit, u64 value_off) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n_half; j += stride) {
+    const u64 i = (((j >> bit) << (bit + 1)) | (j & ((1ull << bit) - 1))) | value_off;
+    dst[i] = src[j];
+  }
+}
+
+constexpr int kReduceBlocks = 2048;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+template <bool MAX>
+__device__ __forceinline__ void block_reduce_store(double v, double* out) {
+  __shared__ double part[kBlock / 64];
+  v = MAX ? wave_max(v) : wave_sum(v);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = part[0];
+    for (int w = 1; w < kBlock / 64; ++w) r = MAX ? fmax(r, part[w]) : r + part[w];
+    out[blockIdx.x] = r;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_norm2_partial(const double2* p, u64 n, double* partial) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double2 v = p[i];
+    acc = fma(v.x, v.x, fma(v.y, v.y, acc));
+  }
+  block_reduce_store<false>(acc, partial);
+}
+
+// kind 0: GHZ, kind 1: GHZ+QFT closed form.  `base` = global index of amp 0.
+__global__ __launch_bounds__(kBlock) void k_closed_form_err(const double2* p, u64 n, int kind,
+                                                            int n_total, u64 base, double* partial) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  const double inv_n = exp2(-(double)n_total);
+  const double amp = exp2(-0.5 * (double)(n_total + 1));
+  const u64 last = (n_total >= 64) ? ~0ull : ((1ull << n_total) - 1);
+  double worst = 0.0;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const u64 y = base + i;
+    double er, ei;
+    if (kind == 0) {
+      er = (y == 0 || y == last) ? 0.70710678118654752440 : 0.0;
+      ei = 0.0;
+    } else {
+      // exp(-2 pi i y / 2^n): y * 2^-n is exact in double for n <= 52
+      double s, c;
+      sincospi(-2.0 * ((double)y * inv_n), &s, &c);
+      er = amp * (1.0 + c);
+      ei = amp * s;
+    }
+    const double2 v = p[i];
+    worst = fmax(worst, hypot(v.x - er, v.y - ei));
+  }
+  block_reduce_store<true>(worst, partial);
+}
+
+static int ensure_scratch(qsim_chunk* c) {
+  if (!c->scratch) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc((void**)&c->scratch, sizeof(double) * kReduceBlocks));
+  }
+  return QSIM_OK;
+}
+
+static unsigned stream_grid(u64 n) {
+  const u64 want = (n + kBlock - 1) / kBlock;
+  return (unsigned)std::min<u64>(std::max<u64>(want, 1), 8192);
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" {
+
+const char* qsim_last_error(void) { return g_err.c_str(); }
+int qsim_version(void) { return 100; }
+
+int qsim_device_count(int* count) {
+  if (!count) return fail(QSIM_ERR_INVALID, "count is null");
+  HIP_TRY(hipGetDeviceCount(count));
+  return QSIM_OK;
+}
+
+static qsim_chunk* new_chunk() {
+  qsim_chunk* c = new qsim_chunk();
+  std::memset(c, 0, sizeof *c);
+  return c;
+}
+
+int qsim_create(int device, int n_local_qubits, qsim_chunk** out) {
+  if (!out) return fail(QSIM_ERR_INVALID, "out is null");
+  if (n_local_qubits < 0 || n_local_qubits > 40)
+    return fail(QSIM_ERR_INVALID, "n_local_qubits %d out of range [0, 40]", n_local_qubits);
+  hipStream_t s;
+  int rc = device_stream(device, &s);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(device));
+  double2* p = nullptr;
+  HIP_TRY(hipMalloc((void**)&p, sizeof(double2) << n_local_qubits));
+  qsim_chunk* c = new_chunk();
+  c->device = device;
+  c->k = n_local_qubits;
+  c->amp = p;
+  c->stream = s;
+  c->owns_memory = true;
+  *out = c;
+  return QSIM_OK;
+}
+
+int qsim_create_view(qsim_chunk* parent, uint64_t offset_amps, int n_local_qubits, qsim_chunk** out) {
+  int rc = check_chunk(parent, "qsim_create_view");
+  if (rc) return rc;
+  if (!out) return fail(QSIM_ERR_INVALID, "out is null");
+  if (n_local_qubits < 0 || n_local_qubits > parent->k)
+    return fail(QSIM_ERR_INVALID, "view of %d qubits does not fit a %d-qubit chunk", n_local_qubits, parent->k);
+  const u64 len = 1ull << n_local_qubits;
+  if (offset_amps % len != 0 || offset_amps + len > amps(parent))
+    return fail(QSIM_ERR_INVALID, "view offset %llu not aligned/inside parent", (u64)offset_amps);
+  qsim_chunk* c = new_chunk();
+  c->device = parent->device;
+  c->k = n_local_qubits;
+  c->amp = parent->amp + offset_amps;
+  c->stream = parent->stream;
+  c->owns_memory = false;
+  c->parent = parent;
+  *out = c;
+  return QSIM_OK;
+}
+
+int qsim_wrap(int device, void* device_ptr, int n_local_qubits, void* stream, qsim_chunk** out) {
+  if (!out || !device_ptr) return fail(QSIM_ERR_INVALID, "null pointer");
+  if (n_local_qubits < 0 || n_local_qubits > 40) return fail(QSIM_ERR_INVALID, "n_local_qubits out of range");
+  if (((uintptr_t)device_ptr & 15) != 0) return fail(QSIM_ERR_INVALID, "device pointer must be 16-byte aligned");
+  qsim_chunk* c = new_chunk();
+  c->device = device;
+  c->k = n_local_qubits;
+  c->amp = (double2*)device_ptr;
+  c->stream = (hipStream_t)stream;
+  c->owns_memory = false;
+  *out = c;
+  return QSIM_OK;
+}
+
+int qsim_destroy(qsim_chunk* c) {
+  if (!c) return QSIM_OK;
+  (void)hipSetDevice(c->device);
+  if (c->have_events) { (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); }
+  if (c->scratch) (void)hipFree(c->scratch);
+  if (c->owns_memory && c->amp) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->amp);
+  }
+  delete c;
+  return QSIM_OK;
+}
+
+int qsim_n_local_qubits(const qsim_chunk* c) { return c ? c->k : -1; }
+void* qsim_device_ptr(const qsim_chunk* c) { return c ? (void*)c->amp : nullptr; }
+
+int qsim_init_zero(qsim_chunk* c, int set_amp0) {
+  int rc = check_chunk(c, "qsim_init_zero");
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_fill_zero, dim3(stream_grid(amps(c))), dim3(kBlock), 0, c->stream, c->amp, amps(c), set_amp0);
+  HIP_TRY(hipGetLastError());
+  return QSIM_OK;
+}
+
+int qsim_norm2(qsim_chunk* c, double* out) {
+  int rc = check_chunk(c, "qsim_norm2");
+  if (rc) return rc;
+  if (!out) return fail(QSIM_ERR_INVALID, "out is null");
+  if ((rc = ensure_scratch(c))) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  const unsigned grid = std::min<unsigned>(stream_grid(amps(c)), kReduceBlocks);
+  hipLaunchKernelGGL(k_norm2_partial, dim3(grid), dim3(kBlock), 0, c->stream, c->amp, amps(c), c->scratch);
+  HIP_TRY(hipGetLastError());
+  std::vector<double> host(grid);
+  HIP_TRY(hipMemcpyAsync(host.data(), c->scratch, sizeof(double) * grid, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  long double total = 0;
+  for (double v : host) total += v;
+  *out = (double)total;
+  return QSIM_OK;
+}
+
+int qsim_init_random(qsim_chunk* c, uint64_t seed) {
+  int rc = check_chunk(c, "qsim_init_random");
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_fill_random, dim3(stream_grid(amps(c))), dim3(kBlock), 0, c->stream, c->amp, amps(c), (u64)seed);
+  HIP_TRY(hipGetLastError());
+  double n2 = 0;
+  if ((rc = qsim_norm2(c, &n2))) return rc;
+  if (!(n2 > 0)) return fail(QSIM_ERR_INVALID, "random state has zero norm");
+  hipLaunchKernelGGL(k_scale, dim3(stream_grid(amps(c))), dim3(kBlock), 0, c->stream, c->amp, amps(c), 1.0 / std::sqrt(n2));
+  HIP_TRY(hipGetLastError());
+  return QSIM_OK;
+}
+
+int qsim_upload(qsim_chunk* c, const double* re_im, uint64_t offset_amps, uint64_t count) {
+  int rc = check_chunk(c, "qsim_upload");
+  if (rc) return rc;
+  if (!re_im && count) return fail(QSIM_ERR_INVALID, "host buffer is null");
+  if (offset_amps > amps(c) || count > amps(c) - offset_amps)
+    return fail(QSIM_ERR_INVALID, "upload range [%llu, +%llu) outside chunk of %llu", (u64)offset_amps, (u64)count, amps(c));
+  if (!count) return QSIM_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(c->amp + offset_amps, re_im, count * sizeof(double2), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QSIM_OK;
+}
+
+int qsim_download(qsim_chunk* c, double* re_im, uint64_t offset_amps, uint64_t count) {
+  int rc = check_chunk(c, "qsim_download");
+  if (rc) return rc;
+  if (!re_im && count) return fail(QSIM_ERR_INVALID, "host buffer is null");
+  if (offset_amps > amps(c) || count > amps(c) - offset_amps)
+    return fail(QSIM_ERR_INVALID, "download range [%llu, +%llu) outside chunk of %llu", (u64)offset_amps, (u64)count, amps(c));
+  if (!count) return QSIM_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(re_im, c->amp + offset_amps, count * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QSIM_OK;
+}
+
+int qsim_copy(qsim_chunk* dst, const qsim_chunk* src) {
+  int rc = check_chunk(dst, "qsim_copy");
+  if (rc || (rc = check_chunk(src, "qsim_copy"))) return rc;
+  if (dst->k != src->k) return fail(QSIM_ERR_INVALID, "qsim_copy: sizes differ");
+  if (dst->amp == src->amp) return QSIM_OK;
+  HIP_TRY(hipSetDevice(dst->device));
+  hipLaunchKernelGGL(k_copy, dim3(stream_grid(amps(dst))), dim3(kBlock), 0, dst->stream, dst->amp, src->amp, amps(dst));
+  HIP_TRY(hipGetLastError());
+  return QSIM_OK;
+}
+
+int qsim_apply_1q(qsim_chunk* c, int qubit, const double U[8]) {
+  int rc = check_chunk(c, "qsim_apply_1q");
+  if (rc || (rc = check_local_qubit(c, qubit))) return rc;
+  if (!U) return fail(QSIM_ERR_INVALID, "U is null");
+  HIP_TRY(hipSetDevice(c->device));
+  Group g = {{c, nullptr, nullptr, nullptr}, 1, c->k};
+  return gate_1q(g, qubit, U, c->stream);
+}
+
+int qsim_apply_2q(qsim_chunk* c, int qa, int qb, const double U[32]) {
+  int rc = check_chunk(c, "qsim_apply_2q");
+  if (rc || (rc = check_local_qubit(c, qa)) || (rc = check_local_qubit(c, qb))) return rc;
+  if (qa == qb) return fail(QSIM_ERR_INVALID, "apply_2q needs two distinct qubits, got %d twice", qa);
+  if (!U) return fail(QSIM_ERR_INVALID, "U is null");
+  HIP_TRY(hipSetDevice(c->device));
+  Group g = {{c, nullptr, nullptr, nullptr}, 1, c->k};
+  return gate_2q(g, qa, qb, U, c->stream);
+}
+
+int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats) {
+  int rc = check_chunk(c, "qsim_apply_ops");
+  if (rc) return rc;
+  if (n_ops < 0 || (n_ops && (!nq || !qubits || !mats))) return fail(QSIM_ERR_INVALID, "bad op list");
+  for (int i = 0; i < n_ops; ++i) {  // validate everything before the first launch
+    if (nq[i] != 1 && nq[i] != 2) return fail(QSIM_ERR_INVALID, "op %d: arity %d", i, nq[i]);
+    for (int j = 0; j < nq[i]; ++j)
+      if ((rc = check_local_qubit(c, qubits[2 * i + j]))) return rc;
+    if (nq[i] == 2 && qubits[2 * i] == qubits[2 * i + 1])
+      return fail(QSIM_ERR_INVALID, "op %d: repeated qubit", i);
+  }
+  for (int i = 0; i < n_ops; ++i) {
+    rc = nq[i] == 1 ? qsim_apply_1q(c, qubits[2 * i], mats + 32 * (size_t)i)
+                    : qsim_apply_2q(c, qubits[2 * i], qubits[2 * i + 1], mats + 32 * (size_t)i);
+    if (rc) return rc;
+  }
+  return QSIM_OK;
+}
+
+int qsim_apply_1q_pair(qsim_chunk* c0, qsim_chunk* c1, const double U[8]) {
+  qsim_chunk* cs[2] = {c0, c1};
+  int rc = check_group(cs, 2, "qsim_apply_1q_pair");
+  if (rc) return rc;
+  if (!U) return fail(QSIM_ERR_INVALID, "U is null");
+  HIP_TRY(hipSetDevice(c0->device));
+  Group g = {{c0, c1, nullptr, nullptr}, 2, c0->k};
+  return gate_1q(g, c0->k, U, c0->stream);
+}
+
+int qsim_apply_2q_pair_qa_local(qsim_chunk* c0, qsim_chunk* c1, int qa, const double U[32]) {
+  qsim_chunk* cs[2] = {c0, c1};
+  int rc = check_group(cs, 2, "qsim_apply_2q_pair_qa_local");
+  if (rc || (rc = check_local_qubit(c0, qa))) return rc;
+  if (!U) return fail(QSIM_ERR_INVALID, "U is null");
+  HIP_TRY(hipSetDevice(c0->device));
+  Group g = {{c0, c1, nullptr, nullptr}, 2, c0->k};
+  return gate_2q(g, qa, c0->k, U, c0->stream);
+}
+
+int qsim_apply_2q_pair_qb_local(qsim_chunk* c0, qsim_chunk* c1, int qb, const double U[32]) {
+  qsim_chunk* cs[2] = {c0, c1};
+  int rc = check_group(cs, 2, "qsim_apply_2q_pair_qb_local");
+  if (rc || (rc = check_local_qubit(c0, qb))) return rc;
+  if (!U) return fail(QSIM_ERR_INVALID, "U is null");
+  HIP_TRY(hipSetDevice(c0->device));
+  Group g = {{c0, c1, nullptr, nullptr}, 2, c0->k};
+  return gate_2q(g, c0->k, qb, U, c0->stream);
+}
+
+int qsim_apply_2q_quad(qsim_chunk* c00, qsim_chunk* c01, qsim_chunk* c10, qsim_chunk* c11, const double U[32]) {
+  qsim_chunk* cs[4] = {c00, c01, c10, c11};
+  int rc = check_group(cs, 4, "qsim_apply_2q_quad");
+  if (rc) return rc;
+  if (!U) return fail(QSIM_ERR_INVALID, "U is null");
+  HIP_TRY(hipSetDevice(c00->device));
+  // chunk index = 2*bit(qa) + bit(qb): qb is virtual bit k, qa is virtual bit k+1
+  Group g = {{c00, c01, c10, c11}, 4, c00->k};
+  return gate_2q(g, c00->k + 1, c00->k, U, c00->stream);
+}
+
+int qsim_pack_half(const qsim_chunk* src, int bit, int value, qsim_chunk* buf) {
+  int rc = check_chunk(src, "qsim_pack_half");
+  if (rc || (rc = check_chunk(buf, "qsim_pack_half"))) return rc;
+  if (bit < 0 || bit >= src->k || buf->k != src->k - 1 || (value != 0 && value != 1))
+    return fail(QSIM_ERR_INVALID, "qsim_pack_half: bit %d / buffer size mismatch", bit);
+  HIP_TRY(hipSetDevice(src->device));
+  const u64 n_half = amps(buf);
+  hipLaunchKernelGGL(k_pack_half, dim3(stream_grid(n_half)), dim3(kBlock), 0, src->stream,
+                     buf->amp, (const double2*)src->amp, n_half, bit, value ? (1ull << bit) : 0ull);
+  HIP_TRY(hipGetLastError());
+  return QSIM_OK;
+}
+
+int qsim_unpack_half(qsim_chunk* dst, int bit, int value, const qsim_chunk* buf) {
+  int rc = check_chunk(dst, "qsim_unpack_half");
+  if (rc || (rc = check_chunk(buf, "qsim_unpack_half"))) return rc;
+  if (bit < 0 || bit >= dst->k || buf->k != dst->k - 1 || (value != 0 && value != 1))
+    return fail(QSIM_ERR_INVALID, "qsim_unpack_half: bit %d / buffer size mismatch", bit);
+  HIP_TRY(hipSetDevice(dst->device));
+  const u64 n_half = amps(buf);
+  hipLaunchKernelGGL(k_unpack_half, dim3(stream_grid(n_half)), dim3(kBlock), 0, dst->stream,
+                     dst->amp, (const double2*)buf->amp, n_half, bit, value ? (1ull << bit) : 0ull);
+  HIP_TRY(hipGetLastError());
+  return QSIM_OK;
+}
+
+int qsim_sync(qsim_chunk* c) {
+  int rc = check_chunk(c, "qsim_sync");
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QSIM_OK;
+}
+
+int qsim_max_abs_err_closed_form(qsim_chunk* c, int kind, int n_total_qubits, uint64_t base_index, double* out) {
+  int rc = check_chunk(c, "qsim_max_abs_err_closed_form");
+  if (rc) return rc;
+  if (!out || (kind != 0 && kind != 1) || n_total_qubits < c->k || n_total_qubits > 52)
+    return fail(QSIM_ERR_INVALID, "qsim_max_abs_err_closed_form: bad arguments");
+  if ((rc = ensure_scratch(c))) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  const unsigned grid = std::min<unsigned>(stream_grid(amps(c)), kReduceBlocks);
+  hipLaunchKernelGGL(k_closed_form_err, dim3(grid), dim3(kBlock), 0, c->stream, c->amp, amps(c), kind,
+                     n_total_qubits, (u64)base_index, c->scratch);
+  HIP_TRY(hipGetLastError());
+  std::vector<double> host(grid);
+  HIP_TRY(hipMemcpyAsync(host.data(), c->scratch, sizeof(double) * grid, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  double worst = 0;
+  for (double v : host) worst = std::max(worst, v);
+  *out = worst;
+  return QSIM_OK;
+}
+
+static int ensure_events(qsim_chunk* c) {
+  if (!c->have_events) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    c->have_events = true;
+  }
+  return QSIM_OK;
+}
+
+int qsim_time_begin(qsim_chunk* c) {
+  int rc = check_chunk(c, "qsim_time_begin");
+  if (rc || (rc = ensure_events(c))) return rc;
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  return QSIM_OK;
+}
+
+int qsim_time_end(qsim_chunk* c, float* elapsed_ms) {
+  int rc = check_chunk(c, "qsim_time_end");
+  if (rc || (rc = ensure_events(c))) return rc;
+  if (!elapsed_ms) return fail(QSIM_ERR_INVALID, "elapsed_ms is null");
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+  return QSIM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+"""HBM-resident chunk handle: the GPU counterpart of the reference's in-RAM numpy chunk
+(wenbo_engine/storage/block_store.py:31, chunk c = amplitudes [c*2^k, (c+1)*2^k)).
+
+A `DeviceChunk` owns (or views, or wraps) 2^k complex128 amplitudes on one MI355X and
+forwards every operation to libqsim_hip.so.  No arithmetic happens in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from quantum_simulations_amd import _lib
+
+
+def _mat_ptr(U: np.ndarray, dim: int):
+    m = np.ascontiguousarray(U, dtype=np.complex128)
+    if m.shape != (dim, dim):
+        raise ValueError(f"expected a {dim}x{dim} matrix, got shape {m.shape}")
+    return m, m.ctypes.data_as(C.c_void_p)
+
+
+def pack_ops(ops) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """[(qubits, U), ...] -> (nq int32[n], qubits int32[2n], mats float64[32n])."""
+    n = len(ops)
+    nq = np.zeros(n, dtype=np.int32)
+    qs = np.zeros(2 * n, dtype=np.int32)
+    mats = np.zeros((n, 16), dtype=np.complex128)
+    for i, (qubits, U) in enumerate(ops):
+        nq[i] = len(qubits)
+        qs[2 * i: 2 * i + len(qubits)] = qubits
+        flat = np.asarray(U, dtype=np.complex128).reshape(-1)
+        if flat.size != (4 if len(qubits) == 1 else 16):
+            raise ValueError(f"op {i}: matrix size {flat.size} does not fit {len(qubits)} qubit(s)")
+        mats[i, : flat.size] = flat
+    return nq, qs, mats
+
+
+class DeviceChunk:
+    """2^k complex128 amplitudes in HBM."""
+
+    def __init__(self, handle: int, k: int, device: int, keep=None):
+        self._h = C.c_void_p(handle)
+        self.k = k
+        self.device = device
+        self._keep = keep  # parent chunk / torch tensor that owns the memory
+
+    # ---- construction -------------------------------------------------------------
+    @classmethod
+    def empty(cls, k: int, device: int = 0) -> "DeviceChunk":
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.qsim_create(device, k, C.byref(h)))
+        return cls(h.value, k, device)
+
+    @classmethod
+    def zero_state(cls, k: int, device: int = 0, set_amp0: bool = True) -> "DeviceChunk":
+        c = cls.empty(k, device)
+        c.init_zero(set_amp0)
+        return c
+
+    @classmethod
+    def from_numpy(cls, arr: np.ndarray, device: int = 0) -> "DeviceChunk":
+        n = arr.shape[0]
+        if arr.ndim != 1 or n < 1 or n & (n - 1):
+            raise ValueError("chunk must be a 1-D array with a power-of-two length")
+        c = cls.empty(n.bit_length() - 1, device)
+        c.upload(arr)
+        return c
+
+    @classmethod
+    def wrap_pointer(cls, ptr: int, k: int, device: int, stream: int = 0, keep=None) -> "DeviceChunk":
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.qsim_wrap(device, C.c_void_p(ptr), k, C.c_void_p(stream), C.byref(h)))
+        return cls(h.value, k, device, keep=keep)
+
+    def view(self, offset_amps: int, k: int) -> "DeviceChunk":
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.qsim_create_view(self._h, offset_amps, k, C.byref(h)))
+        return DeviceChunk(h.value, k, self.device, keep=self)
+
+    def close(self) -> None:
+        if self._h is not None and self._h.value:
+            _lib.load().qsim_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return 1 << self.k
+
+    @property
+    def device_ptr(self) -> int:
+        return _lib.load().qsim_device_ptr(self._h) or 0
+
+    # ---- state I/O ----------------------------------------------------------------
+    def init_zero(self, set_amp0: bool = True) -> None:
+        _lib.check(_lib.load().qsim_init_zero(self._h, 1 if set_amp0 else 0))
+
+    def init_random(self, seed: int) -> None:
+        _lib.check(_lib.load().qsim_init_random(self._h, seed))
+
+    def upload(self, arr: np.ndarray, offset: int = 0) -> None:
+        host = np.ascontiguousarray(arr, dtype=np.complex128)
+        _lib.check(_lib.load().qsim_upload(self._h, host.ctypes.data_as(C.c_void_p), offset, host.size))
+
+    def download(self, offset: int = 0, count: int | None = None) -> np.ndarray:
+        count = len(self) - offset if count is None else count
+        out = np.empty(count, dtype=np.complex128)
+        _lib.check(_lib.load().qsim_download(self._h, out.ctypes.data_as(C.c_void_p), offset, count))
+        return out
+
+    def copy_from(self, other: "DeviceChunk") -> None:
+        _lib.check(_lib.load().qsim_copy(self._h, other._h))
+
+    # ---- gates --------------------------------------------------------------------
+    def apply_1q(self, qubit: int, U: np.ndarray) -> None:
+        m, p = _mat_ptr(U, 2)
+        _lib.check(_lib.load().qsim_apply_1q(self._h, int(qubit), p))
+
+    def apply_2q(self, qa: int, qb: int, U: np.ndarray) -> None:
+        m, p = _mat_ptr(U, 4)
+        _lib.check(_lib.load().qsim_apply_2q(self._h, int(qa), int(qb), p))
+
+    def apply_ops(self, ops) -> None:
+        """One pass: every (qubits, U) of `ops`, in order, in one C call."""
+        if not ops:
+            return
+        nq, qs, mats = pack_ops(ops)
+        _lib.check(_lib.load().qsim_apply_ops(
+            self._h, len(ops), nq.ctypes.data_as(C.c_void_p), qs.ctypes.data_as(C.c_void_p),
+            mats.ctypes.data_as(C.c_void_p)))
+
+    # ---- sync / reductions / timing -------------------------------------------------
+    def sync(self) -> None:
+        _lib.check(_lib.load().qsim_sync(self._h))
+
+    def norm2(self) -> float:
+        out = C.c_double()
+        _lib.check(_lib.load().qsim_norm2(self._h, C.byref(out)))
+        return out.value
+
+    def max_abs_err_closed_form(self, kind: str, n_total: int, base_index: int = 0) -> float:
+        out = C.c_double()
+        code = {"ghz": 0, "ghz_qft": 1}[kind]
+        _lib.check(_lib.load().qsim_max_abs_err_closed_form(self._h, code, n_total, base_index,
+                                                            C.byref(out)))
+        return out.value
+
+    def time_begin(self) -> None:
+        _lib.check(_lib.load().qsim_time_begin(self._h))
+
+    def time_end(self) -> float:
+        ms = C.c_float()
+        _lib.check(_lib.load().qsim_time_end(self._h, C.byref(ms)))
+        return ms.value
+
+    def pack_half(self, bit: int, value: int, buf: "DeviceChunk") -> None:
+        _lib.check(_lib.load().qsim_pack_half(self._h, bit, value, buf._h))
+
+    def unpack_half(self, bit: int, value: int, buf: "DeviceChunk") -> None:
+        _lib.check(_lib.load().qsim_unpack_half(self._h, bit, value, buf._h))
+
+
+def device_count() -> int:
+    n = C.c_int()
+    _lib.check(_lib.load().qsim_device_count(C.byref(n)))
+    return n.value

@@ -1,0 +1,68 @@
+"""Partner-chunk butterflies on the GPU, interface of `wenbo_engine.kernel.cpu_nonlocal`
+(cpu_nonlocal.py:22-67).  Partner chunks are separate HBM windows (two/four
+`DeviceChunk`s on one device, e.g. the local shard and a buffer received over xGMI); the
+kernels read and write all of them in one launch.  numpy chunks are accepted too
+(upload -> kernel -> download in place), for drop-in use and for the parity tests.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from quantum_simulations_amd import _lib
+from quantum_simulations_amd.kernel.device import DeviceChunk, _mat_ptr
+
+
+def _on_device(chunks, fn) -> None:
+    if all(isinstance(c, DeviceChunk) for c in chunks):
+        fn(list(chunks))
+        return
+    if any(isinstance(c, DeviceChunk) for c in chunks):
+        raise TypeError("mixing DeviceChunk and numpy chunks is not supported")
+    n = len(chunks[0])
+    if any(len(c) != n for c in chunks):
+        raise ValueError("partner chunks must have equal length")
+    k = n.bit_length() - 1
+    # one allocation, one window per partner (like chunks of one state buffer)
+    parent = DeviceChunk.empty(k + (len(chunks).bit_length() - 1))
+    try:
+        views = []
+        for i, c in enumerate(chunks):
+            parent.upload(c, offset=i * n)
+            views.append(parent.view(i * n, k))
+        fn(views)
+        for i, c in enumerate(chunks):
+            c[:] = parent.download(i * n, n)
+        for v in views:
+            v.close()
+    finally:
+        parent.close()
+
+
+def apply_1q_pair(c0, c1, U: np.ndarray) -> None:
+    """1-qubit gate whose qubit is the partner bit; c1 has the bit set."""
+    m, p = _mat_ptr(U, 2)
+    _on_device([c0, c1], lambda d: _lib.check(
+        _lib.load().qsim_apply_1q_pair(d[0]._h, d[1]._h, p)))
+
+
+def apply_2q_pair_qa_local(c0, c1, qa: int, U: np.ndarray) -> None:
+    """2-qubit gate, qa local, qb = partner bit (LSB of the 4x4 index)."""
+    m, p = _mat_ptr(U, 4)
+    _on_device([c0, c1], lambda d: _lib.check(
+        _lib.load().qsim_apply_2q_pair_qa_local(d[0]._h, d[1]._h, int(qa), p)))
+
+
+def apply_2q_pair_qb_local(c0, c1, qb: int, U: np.ndarray) -> None:
+    """2-qubit gate, qa = partner bit (MSB of the 4x4 index), qb local."""
+    m, p = _mat_ptr(U, 4)
+    _on_device([c0, c1], lambda d: _lib.check(
+        _lib.load().qsim_apply_2q_pair_qb_local(d[0]._h, d[1]._h, int(qb), p)))
+
+
+def apply_2q_quad(c00, c01, c10, c11, U: np.ndarray) -> None:
+    """2-qubit gate with both qubits partner bits; argument order = (qa bit, qb bit)."""
+    m, p = _mat_ptr(U, 4)
+    _on_device([c00, c01, c10, c11], lambda d: _lib.check(
+        _lib.load().qsim_apply_2q_quad(d[0]._h, d[1]._h, d[2]._h, d[3]._h, p)))

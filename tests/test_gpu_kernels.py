@@ -1,0 +1,251 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the
+reference's golden vectors.  fp64 tolerance: 1e-12 per kernel call (the oracle and the GPU
+differ only by FMA contraction / summation order, ~1e-16 relative); circuits 1e-10 as the
+north star states."""
+import numpy as np
+import pytest
+
+from oracle import dense_oracle as orc
+from tests.golden_io import golden_circuits, npz
+
+pytestmark = pytest.mark.gpu
+
+ATOL_KERNEL = 1e-12
+ATOL_CIRCUIT = 1e-10
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from quantum_simulations_amd.kernel import gpu_local, gpu_nonlocal, ref_dense
+    from quantum_simulations_amd.kernel.device import DeviceChunk, device_count
+    assert device_count() >= 1
+
+    class NS:
+        pass
+    ns = NS()
+    ns.local, ns.nonlocal_, ns.ref_dense, ns.DeviceChunk = gpu_local, gpu_nonlocal, ref_dense, DeviceChunk
+    return ns
+
+
+def _rand_state(n, seed):
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    return (v / np.linalg.norm(v)).astype(np.complex128)
+
+
+def _rand_unitary(dim, seed):
+    rng = np.random.default_rng(seed)
+    z = rng.standard_normal((dim, dim)) + 1j * rng.standard_normal((dim, dim))
+    q, r = np.linalg.qr(z)
+    return q * (np.diag(r) / np.abs(np.diag(r)))
+
+
+# ---------------------------------------------------------------- golden kernels (G3)
+def test_golden_apply_1q(hip):
+    z = npz("kernels.npz")
+    for key in sorted(k for k in z if k.startswith("k1|")):
+        _, gname, q = key.split("|")
+        chunk = z["chunk_in"].copy()
+        hip.local.apply_1q(chunk, int(q[2:]), z[f"m1_{gname}"])
+        np.testing.assert_allclose(chunk, z[key], rtol=0, atol=ATOL_KERNEL, err_msg=key)
+
+
+def test_golden_apply_2q(hip):
+    z = npz("kernels.npz")
+    for key in sorted(k for k in z if k.startswith("k2|")):
+        _, gname, qa, qb = key.split("|")
+        chunk = z["chunk_in"].copy()
+        hip.local.apply_2q(chunk, int(qa[3:]), int(qb[3:]), z[f"m2_{gname}"])
+        np.testing.assert_allclose(chunk, z[key], rtol=0, atol=ATOL_KERNEL, err_msg=key)
+
+
+def test_golden_nonlocal(hip):
+    z = npz("kernels.npz")
+    quad = [z[f"nl_in_{i}"] for i in range(4)]
+    for name in ("H", "U1"):
+        c0, c1 = quad[0].copy(), quad[1].copy()
+        hip.nonlocal_.apply_1q_pair(c0, c1, z[f"m1_{name}"])
+        np.testing.assert_allclose(c0, z[f"nl|1q_pair|{name}|c0"], rtol=0, atol=ATOL_KERNEL)
+        np.testing.assert_allclose(c1, z[f"nl|1q_pair|{name}|c1"], rtol=0, atol=ATOL_KERNEL)
+    for name in ("CNOT", "CUG3", "U2", "SWAP", "CR3"):
+        U = z[f"m2_{name}"]
+        for q in (0, 3, 5):
+            for fn, tag in ((hip.nonlocal_.apply_2q_pair_qa_local, "qa_local"),
+                            (hip.nonlocal_.apply_2q_pair_qb_local, "qb_local")):
+                c0, c1 = quad[0].copy(), quad[1].copy()
+                fn(c0, c1, q, U)
+                np.testing.assert_allclose(c0, z[f"nl|{tag}|{name}|q={q}|c0"], rtol=0, atol=ATOL_KERNEL)
+                np.testing.assert_allclose(c1, z[f"nl|{tag}|{name}|q={q}|c1"], rtol=0, atol=ATOL_KERNEL)
+        cs = [c.copy() for c in quad]
+        hip.nonlocal_.apply_2q_quad(*cs, U)
+        for i, c in enumerate(cs):
+            np.testing.assert_allclose(c, z[f"nl|quad|{name}|c{i}"], rtol=0, atol=ATOL_KERNEL)
+
+
+# ---------------------------------------------------------------- golden circuits (G2)
+def test_golden_circuits(hip):
+    states = npz("states.npz")
+    for name, cd in golden_circuits().items():
+        got = hip.ref_dense.simulate(cd)
+        np.testing.assert_allclose(got, states[name], rtol=0, atol=ATOL_CIRCUIT, err_msg=name)
+
+
+# ---------------------------------------------------------------- vs oracle, every qubit
+@pytest.mark.parametrize("n", [1, 2, 5, 9, 14])
+def test_every_1q_target_vs_oracle(hip, n):
+    psi0 = _rand_state(n, 100 + n)
+    mats = {"H": orc.gate_matrix("H"), "X": orc.gate_matrix("X"), "T": orc.gate_matrix("T"),
+            "Z": orc.gate_matrix("Z"), "RY": orc.gate_matrix("RY", {"theta": 0.77}),
+            "U": _rand_unitary(2, n), "D": np.diag(np.exp(1j * np.array([0.3, 1.1])))}
+    dev = hip.DeviceChunk.from_numpy(psi0)
+    for gname, U in mats.items():
+        for q in range(n):
+            want = psi0.copy()
+            orc.apply_1q(want, q, U)
+            dev.upload(psi0)
+            dev.apply_1q(q, U)
+            np.testing.assert_allclose(dev.download(), want, rtol=0, atol=ATOL_KERNEL,
+                                       err_msg=f"{gname} q={q} n={n}")
+    dev.close()
+
+
+@pytest.mark.parametrize("n", [2, 3, 7, 11])
+def test_every_2q_pair_vs_oracle(hip, n):
+    psi0 = _rand_state(n, 200 + n)
+    mats = {k: orc.gate_matrix(k, p) for k, p in
+            (("CNOT", {}), ("CZ", {}), ("CY", {}), ("SWAP", {}), ("CR", {"k": 3}),
+             ("CU", {"U": orc.gate_matrix("G", {"p": 3}), "exponent": 1}))}
+    mats["U"] = _rand_unitary(4, n)
+    mats["CTRL_B"] = mats["CNOT"][np.ix_([0, 2, 1, 3], [0, 2, 1, 3])]  # control on qb
+    mats["DIAG"] = np.diag(np.exp(1j * np.array([0.1, 0.2, 0.3, 0.4])))
+    dev = hip.DeviceChunk.from_numpy(psi0)
+    pairs = [(a, b) for a in range(n) for b in range(n) if a != b]
+    if n > 7:
+        rng = np.random.default_rng(n)
+        pairs = [pairs[i] for i in rng.choice(len(pairs), size=40, replace=False)]
+    for gname, U in mats.items():
+        for qa, qb in pairs:
+            want = psi0.copy()
+            orc.apply_2q(want, qa, qb, U)
+            dev.upload(psi0)
+            dev.apply_2q(qa, qb, U)
+            np.testing.assert_allclose(dev.download(), want, rtol=0, atol=ATOL_KERNEL,
+                                       err_msg=f"{gname} qa={qa} qb={qb} n={n}")
+    dev.close()
+
+
+def test_nonlocal_vs_oracle_all_local_bits(hip):
+    k = 7
+    chunks = [_rand_state(k, 300 + i) for i in range(4)]
+    U4s = {"U": _rand_unitary(4, 9), "CNOT": orc.gate_matrix("CNOT"), "CZ": orc.gate_matrix("CZ"),
+           "SWAP": orc.gate_matrix("SWAP"), "CTRL_B": orc.gate_matrix("CNOT")[np.ix_([0, 2, 1, 3], [0, 2, 1, 3])]}
+    for name, U in U4s.items():
+        for q in range(k):
+            for fo, fh in ((orc.apply_2q_pair_qa_local, hip.nonlocal_.apply_2q_pair_qa_local),
+                           (orc.apply_2q_pair_qb_local, hip.nonlocal_.apply_2q_pair_qb_local)):
+                w0, w1 = chunks[0].copy(), chunks[1].copy()
+                fo(w0, w1, q, U)
+                g0, g1 = chunks[0].copy(), chunks[1].copy()
+                fh(g0, g1, q, U)
+                np.testing.assert_allclose(g0, w0, rtol=0, atol=ATOL_KERNEL, err_msg=f"{name} q={q}")
+                np.testing.assert_allclose(g1, w1, rtol=0, atol=ATOL_KERNEL, err_msg=f"{name} q={q}")
+        want = [c.copy() for c in chunks]
+        orc.apply_2q_quad(*want, U)
+        got = [c.copy() for c in chunks]
+        hip.nonlocal_.apply_2q_quad(*got, U)
+        for g, w in zip(got, want):
+            np.testing.assert_allclose(g, w, rtol=0, atol=ATOL_KERNEL)
+    for U in (orc.gate_matrix("H"), orc.gate_matrix("T"), _rand_unitary(2, 4)):
+        w0, w1 = chunks[0].copy(), chunks[1].copy()
+        orc.apply_1q_pair(w0, w1, U)
+        g0, g1 = chunks[0].copy(), chunks[1].copy()
+        hip.nonlocal_.apply_1q_pair(g0, g1, U)
+        np.testing.assert_allclose(g0, w0, rtol=0, atol=ATOL_KERNEL)
+        np.testing.assert_allclose(g1, w1, rtol=0, atol=ATOL_KERNEL)
+
+
+# ---------------------------------------------------------------- interface behaviour
+def test_non_local_raises(hip):  # reference test_kernel_vs_ref.py:35-43
+    chunk = np.zeros(4, dtype=np.complex128)
+    chunk[0] = 1.0
+    with pytest.raises(NotImplementedError, match="non-local"):
+        hip.local.apply_1q(chunk, 2, orc.gate_matrix("H"))
+    dev = hip.DeviceChunk.zero_state(2)
+    with pytest.raises(NotImplementedError, match="non-local"):
+        dev.apply_1q(2, orc.gate_matrix("H"))           # raised by the C ABI itself
+    with pytest.raises(NotImplementedError, match="non-local"):
+        dev.apply_2q(0, 5, orc.gate_matrix("CNOT"))
+    with pytest.raises(ValueError):
+        dev.apply_2q(1, 1, orc.gate_matrix("CNOT"))
+    dev.close()
+
+
+def test_complex64_chunk_keeps_dtype(hip):
+    rng = np.random.default_rng(3)
+    c = (rng.standard_normal(64) + 1j * rng.standard_normal(64)).astype(np.complex64)
+    want = c.copy()
+    orc.apply_1q(want, 3, orc.gate_matrix("H"))
+    hip.local.apply_1q(c, 3, orc.gate_matrix("H"))
+    assert c.dtype == np.complex64
+    np.testing.assert_allclose(c, want, rtol=0, atol=1e-6)
+
+
+def test_kat_endianness_bell_ghz(hip):
+    psi = hip.ref_dense.simulate({"number_of_qubits": 3, "gates": [{"qubits": [0], "gate": "X"}]})
+    assert abs(psi[1] - 1) < 1e-12
+    psi = hip.ref_dense.simulate({"number_of_qubits": 4, "gates": [{"qubits": [3], "gate": "X"}]})
+    assert abs(psi[8] - 1) < 1e-12
+    s2 = 1 / np.sqrt(2)
+    psi = hip.ref_dense.simulate(golden_circuits()["bell_2q"])
+    np.testing.assert_allclose(psi, [s2, 0, 0, s2], atol=1e-12)
+
+
+def test_apply_ops_pass_and_norm(hip):
+    from quantum_simulations_amd.circuit.fusion import batch_levels
+    from quantum_simulations_amd.circuit.io import levelize, validate_circuit_dict
+    from quantum_simulations_amd.circuits import random_1q_cx_circuit
+    cd = validate_circuit_dict(random_1q_cx_circuit(12, depth=10, seed=4))
+    want = orc.simulate(cd)
+    dev = hip.DeviceChunk.zero_state(12)
+    for p in batch_levels(levelize(cd), 12):
+        dev.apply_ops(p["local_ops"])
+    np.testing.assert_allclose(dev.download(), want, rtol=0, atol=ATOL_CIRCUIT)
+    assert abs(dev.norm2() - 1.0) < 1e-12
+    dev.close()
+
+
+# ---------------------------------------------------------------- full-size properties
+def test_ghz_closed_form_on_device_26q(hip):
+    from quantum_simulations_amd.circuits import generate_ghz_circuit, generate_ghz_qft
+    n = 26
+    dev = hip.ref_dense.simulate_on_device(generate_ghz_circuit(n))
+    assert dev.max_abs_err_closed_form("ghz", n) < ATOL_CIRCUIT
+    dev.close()
+    n = 20
+    dev = hip.ref_dense.simulate_on_device(generate_ghz_qft(n))
+    assert dev.max_abs_err_closed_form("ghz_qft", n) < ATOL_CIRCUIT
+    got = dev.download(0, 4096)
+    np.testing.assert_allclose(got, orc.ghz_qft_closed_form(n, np.arange(4096)), atol=ATOL_CIRCUIT)
+    dev.close()
+
+
+def test_full_size_28q_unitarity_roundtrip(hip):
+    """BASELINE config-2 size: H.H = I and X.X = I on every qubit class, norm preserved,
+    random state reproduced to 1e-12 after the round trip (size-independent properties)."""
+    n = 28
+    dev = hip.DeviceChunk.empty(n)
+    dev.init_random(28)
+    before = dev.download(0, 1 << 16)
+    tail = dev.download((1 << n) - 4096, 4096)
+    assert abs(dev.norm2() - 1.0) < 1e-12
+    H, CX = orc.gate_matrix("H"), orc.gate_matrix("CNOT")
+    for q in (0, 3, 5, 6, 13, 27):
+        dev.apply_1q(q, H)
+        dev.apply_1q(q, H)
+    for qa, qb in ((0, 1), (27, 0), (5, 20), (26, 27)):
+        dev.apply_2q(qa, qb, CX)
+        dev.apply_2q(qa, qb, CX)
+    assert abs(dev.norm2() - 1.0) < 1e-12
+    np.testing.assert_allclose(dev.download(0, 1 << 16), before, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(dev.download((1 << n) - 4096, 4096), tail, rtol=0, atol=1e-12)
+    dev.close()
