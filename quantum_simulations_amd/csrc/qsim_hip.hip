@@ -97,12 +97,47 @@ __device__ __forceinline__ double2 cfma(double2 a, double2 b, double2 acc) {
   return make_double2(fma(a.x, b.x, fma(-a.y, b.y, acc.x)), fma(a.x, b.y, fma(a.y, b.x, acc.y)));
 }
 
+// Streaming (non-temporal) 16-byte accesses: `global_load/store_dwordx4 ... nt`.  Measured on
+// MI355X (profiles/r01_bw_probe.txt): +6..15 % on the in-place butterfly when every wave
+// instruction covers whole 128-B lines; harmful when a line is shared by two instructions,
+// so the launcher only selects NT when the lowest removed index bit is >= 3.
+template <bool NT>
+__device__ __forceinline__ double2 ld_amp(const double2* p) {
+  if (NT) {
+    double2 v;
+    v.x = __builtin_nontemporal_load(&p->x);
+    v.y = __builtin_nontemporal_load(&p->y);
+    return v;
+  }
+  return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st_amp(double2* p, double2 v) {
+  if (NT) {
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+  } else {
+    *p = v;
+  }
+}
+
 // Re-insert zero bits at ascending positions pos[0..npos) of a compressed index.
 __device__ __forceinline__ u64 expand_index(u64 c, int npos, int p0, int p1, int p2) {
   if (npos > 0) c = ((c >> p0) << (p0 + 1)) | (c & ((1ull << p0) - 1));
   if (npos > 1) c = ((c >> p1) << (p1 + 1)) | (c & ((1ull << p1) - 1));
   if (npos > 2) c = ((c >> p2) << (p2 + 1)) | (c & ((1ull << p2) - 1));
   return c;
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one).  With SWZ
+// each XCD walks one contiguous eighth of the work-item space instead of every eighth block.
+template <bool SWZ>
+__device__ __forceinline__ u64 logical_block() {
+  if (SWZ) {
+    const u64 per_xcd = gridDim.x >> 3;
+    return (u64)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  }
+  return blockIdx.x;
 }
 
 template <int NM>
@@ -116,9 +151,10 @@ struct GateArgs {
 
 constexpr int kBlock = 256;
 
-template <int NM, int ITEMS>
+// All target bits resolved in registers: a work item owns NM amplitudes.
+template <int NM, int ITEMS, bool NT, bool SWZ>
 __global__ __launch_bounds__(kBlock) void k_gate(const GateArgs<NM> a) {
-  const u64 first = ((u64)blockIdx.x * ITEMS) * kBlock + threadIdx.x;
+  const u64 first = (logical_block<SWZ>() * ITEMS) * kBlock + threadIdx.x;
   u64 idx[ITEMS];
   bool live[ITEMS];
   double2 x[ITEMS][NM];
@@ -132,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_gate(const GateArgs<NM> a) {
   for (int r = 0; r < ITEMS; ++r) {
     if (live[r]) {
 #pragma unroll
-      for (int m = 0; m < NM; ++m) x[r][m] = a.member[m][idx[r]];
+      for (int m = 0; m < NM; ++m) x[r][m] = ld_amp<NT>(a.member[m] + idx[r]);
     }
   }
 #pragma unroll
@@ -143,8 +179,97 @@ __global__ __launch_bounds__(kBlock) void k_gate(const GateArgs<NM> a) {
         double2 acc = cmul(a.u[row * NM], x[r][0]);
 #pragma unroll
         for (int col = 1; col < NM; ++col) acc = cfma(a.u[row * NM + col], x[r][col], acc);
-        a.member[row][idx[r]] = acc;
+        st_amp<NT>(a.member[row] + idx[r], acc);
       }
+    }
+  }
+}
+
+// Low target bits (index bit < 3: partners share a 128-B line) are resolved across lanes:
+// every lane loads its own amplitude(s) with whole-line coalescing, fetches the partner
+// values with ds_bpermute (`__shfl_xor`) and computes only its own output row.
+//   NMR register members x 2^NSH lane states; canonical matrix index = (r << NSH) | s,
+//   s bit b <-> lane bit lane_bit[b].
+template <int NMR, int NSH>
+struct ShuffleArgs {
+  double2* member[NMR];
+  u64 count;
+  int npos;
+  int pos[3];
+  int lane_bit[2];
+  double2 u[(NMR << NSH) * (NMR << NSH)];
+};
+
+template <int NMR, int NSH, int ITEMS, bool NT>
+__global__ __launch_bounds__(kBlock) void k_gate_shuffle(const ShuffleArgs<NMR, NSH> a) {
+  constexpr int NL = 1 << NSH;
+  constexpr int DIM = NMR << NSH;
+  const int lane = threadIdx.x & 63;
+  int s = 0;
+#pragma unroll
+  for (int b = 0; b < NSH; ++b) s |= ((lane >> a.lane_bit[b]) & 1) << b;
+  // per-lane coefficients: coef[r][r2][d] = U[(r<<NSH)|s][(r2<<NSH)|(s^d)]
+  double2 coef[NMR][NMR][NL];
+  int xmask[NL];
+#pragma unroll
+  for (int d = 0; d < NL; ++d) {
+    xmask[d] = 0;
+#pragma unroll
+    for (int b = 0; b < NSH; ++b) xmask[d] |= ((d >> b) & 1) << a.lane_bit[b];
+#pragma unroll
+    for (int r = 0; r < NMR; ++r)
+#pragma unroll
+      for (int r2 = 0; r2 < NMR; ++r2) {
+        double2 c = a.u[((r << NSH) | 0) * DIM + ((r2 << NSH) | (0 ^ d))];
+#pragma unroll
+        for (int sv = 1; sv < NL; ++sv) {
+          const double2 alt = a.u[((r << NSH) | sv) * DIM + ((r2 << NSH) | (sv ^ d))];
+          c.x = (s == sv) ? alt.x : c.x;
+          c.y = (s == sv) ? alt.y : c.y;
+        }
+        coef[r][r2][d] = c;
+      }
+  }
+  const u64 first = ((u64)blockIdx.x * ITEMS) * kBlock + threadIdx.x;
+  u64 idx[ITEMS];
+  bool live[ITEMS];
+  double2 x[ITEMS][NMR];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const u64 c = first + (u64)it * kBlock;
+    live[it] = c < a.count;
+    idx[it] = expand_index(c, a.npos, a.pos[0], a.pos[1], a.pos[2]);
+#pragma unroll
+    for (int r = 0; r < NMR; ++r) x[it][r] = make_double2(0.0, 0.0);
+  }
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    if (live[it]) {
+#pragma unroll
+      for (int r = 0; r < NMR; ++r) x[it][r] = ld_amp<NT>(a.member[r] + idx[it]);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    double2 out[NMR];
+#pragma unroll
+    for (int r = 0; r < NMR; ++r) out[r] = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int r2 = 0; r2 < NMR; ++r2) {
+#pragma unroll
+      for (int d = 0; d < NL; ++d) {
+        double2 v = x[it][r2];
+        if (d != 0) {  // all 64 lanes take part (inactive tail lanes hold zeros)
+          v.x = __shfl_xor(x[it][r2].x, xmask[d], 64);
+          v.y = __shfl_xor(x[it][r2].y, xmask[d], 64);
+        }
+#pragma unroll
+        for (int r = 0; r < NMR; ++r) out[r] = cfma(coef[r][r2][d], v, out[r]);
+      }
+    }
+    if (live[it]) {
+#pragma unroll
+      for (int r = 0; r < NMR; ++r) st_amp<NT>(a.member[r] + idx[it], out[r]);
     }
   }
 }
@@ -157,16 +282,39 @@ struct Group {        // 1, 2 or 4 chunks forming a virtual index space of k + g
 };
 
 struct Plan {
-  int nm;                   // 1, 2, 4
+  int nm;                   // register members: 1, 2, 4
+  int nsh;                  // lane-resolved targets: 0, 1, 2
   double2* member[4];
-  u64 count;
+  u64 count;                // work items
   int npos;
   int pos[3];
-  double2 u[16];
+  int lane_bit[2];
+  double2 u[16];            // (nm << nsh)^2 canonical matrix
+  int low_removed;          // lowest removed index bit (64 if none)
+  int high_removed;         // highest removed index bit (-1 if none)
 };
 
 static inline bool is_zero(double re, double im) { return re == 0.0 && im == 0.0; }
 static inline bool is_one(double re, double im) { return re == 1.0 && im == 0.0; }
+
+// Index bits below this are resolved across lanes (partners share one 128-B line).
+constexpr int kLaneCut = 3;
+
+// Tunables (environment overrides are for profiling sweeps only).
+struct Tuning {
+  int swz_cut = 64;   // XCD-contiguous block order when the highest removed bit is below this (r01 scan: always)
+  int force_nt = -1;  // -1 auto, 0 never, 1 always
+  int items = 0;      // 0 auto
+  Tuning() {
+    if (const char* e = getenv("QSIM_SWZ_CUT")) swz_cut = atoi(e);
+    if (const char* e = getenv("QSIM_NT")) force_nt = atoi(e);
+    if (const char* e = getenv("QSIM_ITEMS")) items = atoi(e);
+  }
+};
+static const Tuning& tuning() {
+  static Tuning t;
+  return t;
+}
 
 // Resolve a virtual offset (bits >= k select the chunk) to a device pointer.
 static double2* resolve(const Group& g, u64 voff) {
@@ -174,33 +322,68 @@ static double2* resolve(const Group& g, u64 voff) {
   return g.c[ci]->amp + (voff & ((1ull << g.k) - 1));
 }
 
-// Build a plan: `targets` (matrix order, MSB first), `fixed` one-bits, nm x nm matrix.
+// Build a plan: `targets` (matrix order, MSB first), `fixed` one-bits, 2^nt x 2^nt matrix.
 static int make_plan(const Group& g, const int* targets, int nt, const int* fixed, int nf,
                      const double* mat, Plan* p) {
-  p->nm = 1 << nt;
+  bool lane_t[2] = {false, false};
+  int nr_bits = 0, nsh = 0;
+  for (int j = 0; j < nt; ++j) {
+    lane_t[j] = targets[j] < g.k && targets[j] < kLaneCut;
+    if (lane_t[j]) ++nsh; else ++nr_bits;
+  }
+  p->nm = 1 << nr_bits;
+  p->nsh = nsh;
   int removed[4];
   int nr = 0;
-  for (int i = 0; i < nt; ++i) if (targets[i] < g.k) removed[nr++] = targets[i];
+  for (int j = 0; j < nt; ++j) if (!lane_t[j] && targets[j] < g.k) removed[nr++] = targets[j];
   for (int i = 0; i < nf; ++i) if (fixed[i] < g.k) removed[nr++] = fixed[i];
   if (nr > 3) return fail(QSIM_ERR_INVALID, "internal: more than 3 removed bits");
   std::sort(removed, removed + nr);
   p->npos = nr;
   for (int i = 0; i < 3; ++i) p->pos[i] = i < nr ? removed[i] : 0;
+  p->low_removed = nr ? removed[0] : 64;
+  p->high_removed = nr ? removed[nr - 1] : -1;
   p->count = 1ull << (g.k - nr);
+  // rank of each target among register / lane targets, in matrix (MSB-first) order
+  int reg_rank[2] = {0, 0}, lane_rank[2] = {0, 0};
+  for (int j = 0, rr = 0, lr = 0; j < nt; ++j) {
+    if (lane_t[j]) lane_rank[j] = lr++; else reg_rank[j] = rr++;
+  }
+  p->lane_bit[0] = p->lane_bit[1] = 0;
+  for (int j = 0; j < nt; ++j) {
+    if (!lane_t[j]) continue;
+    int below = 0;
+    for (int i = 0; i < nr; ++i) if (removed[i] < targets[j]) ++below;
+    p->lane_bit[nsh - 1 - lane_rank[j]] = targets[j] - below;
+  }
   u64 fixed_off = 0;
   for (int i = 0; i < nf; ++i) fixed_off |= 1ull << fixed[i];
-  for (int m = 0; m < p->nm; ++m) {
+  for (int r = 0; r < p->nm; ++r) {
     u64 off = fixed_off;
-    for (int t = 0; t < nt; ++t)
-      if ((m >> (nt - 1 - t)) & 1) off |= 1ull << targets[t];
-    p->member[m] = resolve(g, off);
+    for (int j = 0; j < nt; ++j)
+      if (!lane_t[j] && ((r >> (nr_bits - 1 - reg_rank[j])) & 1)) off |= 1ull << targets[j];
+    p->member[r] = resolve(g, off);
   }
-  for (int i = 0; i < p->nm * p->nm; ++i) p->u[i] = make_double2(mat[2 * i], mat[2 * i + 1]);
+  // canonical index of matrix index m: (r << nsh) | s
+  const int dim = 1 << nt;
+  int canon[4];
+  for (int m = 0; m < dim; ++m) {
+    int r = 0, s = 0;
+    for (int j = 0; j < nt; ++j) {
+      const int bit = (m >> (nt - 1 - j)) & 1;
+      if (lane_t[j]) s |= bit << (nsh - 1 - lane_rank[j]);
+      else r |= bit << (nr_bits - 1 - reg_rank[j]);
+    }
+    canon[m] = (r << nsh) | s;
+  }
+  for (int a = 0; a < dim; ++a)
+    for (int b = 0; b < dim; ++b)
+      p->u[canon[a] * dim + canon[b]] = make_double2(mat[2 * (a * dim + b)], mat[2 * (a * dim + b) + 1]);
   return QSIM_OK;
 }
 
-template <int NM, int ITEMS>
-static int launch_plan_t(const Plan& p, hipStream_t stream) {
+template <int NM, int ITEMS, bool NT, bool SWZ>
+static int launch_reg(const Plan& p, hipStream_t stream) {
   GateArgs<NM> a;
   for (int m = 0; m < NM; ++m) a.member[m] = p.member[m];
   a.count = p.count;
@@ -209,17 +392,68 @@ static int launch_plan_t(const Plan& p, hipStream_t stream) {
   for (int i = 0; i < NM * NM; ++i) a.u[i] = p.u[i];
   const u64 per_block = (u64)kBlock * ITEMS;
   const u64 blocks = (p.count + per_block - 1) / per_block;
-  if (blocks > 0x7fffffffull) return fail(QSIM_ERR_INVALID, "grid too large");
-  hipLaunchKernelGGL((k_gate<NM, ITEMS>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, a);
+  hipLaunchKernelGGL((k_gate<NM, ITEMS, NT, SWZ>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, a);
   HIP_TRY(hipGetLastError());
   return QSIM_OK;
 }
 
+template <int NMR, int NSH, int ITEMS, bool NT>
+static int launch_shuffle(const Plan& p, hipStream_t stream) {
+  ShuffleArgs<NMR, NSH> a;
+  for (int m = 0; m < NMR; ++m) a.member[m] = p.member[m];
+  a.count = p.count;
+  a.npos = p.npos;
+  for (int i = 0; i < 3; ++i) a.pos[i] = p.pos[i];
+  a.lane_bit[0] = p.lane_bit[0];
+  a.lane_bit[1] = p.lane_bit[1];
+  constexpr int DIM = NMR << NSH;
+  for (int i = 0; i < DIM * DIM; ++i) a.u[i] = p.u[i];
+  const u64 per_block = (u64)kBlock * ITEMS;
+  const u64 blocks = (p.count + per_block - 1) / per_block;
+  hipLaunchKernelGGL((k_gate_shuffle<NMR, NSH, ITEMS, NT>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, a);
+  HIP_TRY(hipGetLastError());
+  return QSIM_OK;
+}
+
+template <int NM, int ITEMS>
+static int launch_reg_flags(const Plan& p, bool nt, bool swz, hipStream_t stream) {
+  if (nt) return swz ? launch_reg<NM, ITEMS, true, true>(p, stream) : launch_reg<NM, ITEMS, true, false>(p, stream);
+  return swz ? launch_reg<NM, ITEMS, false, true>(p, stream) : launch_reg<NM, ITEMS, false, false>(p, stream);
+}
+
+template <int NM>
+static int launch_reg_items(const Plan& p, int items, bool nt, bool swz, hipStream_t stream) {
+  switch (items) {
+    case 1: return launch_reg_flags<NM, 1>(p, nt, swz, stream);
+    case 2: return launch_reg_flags<NM, 2>(p, nt, swz, stream);
+    default: return launch_reg_flags<NM, 4>(p, nt, swz, stream);
+  }
+}
+
 static int launch_plan(const Plan& p, hipStream_t stream) {
+  const Tuning& t = tuning();
+  // NT only when every wave instruction covers whole 128-B lines
+  bool nt = p.low_removed >= 3;
+  if (t.force_nt >= 0) nt = t.force_nt != 0;
+  if (p.count > (0x7fffffffull * kBlock)) return fail(QSIM_ERR_INVALID, "grid too large");
+  if (p.nsh > 0) {
+    if (p.nm == 1 && p.nsh == 1) return nt ? launch_shuffle<1, 1, 2, true>(p, stream) : launch_shuffle<1, 1, 2, false>(p, stream);
+    if (p.nm == 1 && p.nsh == 2) return nt ? launch_shuffle<1, 2, 2, true>(p, stream) : launch_shuffle<1, 2, 2, false>(p, stream);
+    if (p.nm == 2 && p.nsh == 1) return nt ? launch_shuffle<2, 1, 2, true>(p, stream) : launch_shuffle<2, 1, 2, false>(p, stream);
+    return fail(QSIM_ERR_INVALID, "internal: bad shuffle plan %d/%d", p.nm, p.nsh);
+  }
+  int items = p.nm == 4 ? 1 : 2;
+  bool swz = p.high_removed < t.swz_cut;
+  if (!swz) items *= 2;
+  if (t.items > 0) items = t.items;
+  if (items != 1 && items != 2) items = 4;
+  const u64 per_block = (u64)kBlock * items;
+  const u64 blocks = (p.count + per_block - 1) / per_block;
+  if (blocks < 64 || (blocks & 7)) swz = false;
   switch (p.nm) {
-    case 1: return launch_plan_t<1, 8>(p, stream);
-    case 2: return launch_plan_t<2, 4>(p, stream);
-    case 4: return launch_plan_t<4, 2>(p, stream);
+    case 1: return launch_reg_items<1>(p, items, nt, swz, stream);
+    case 2: return launch_reg_items<2>(p, items, nt, swz, stream);
+    case 4: return launch_reg_items<4>(p, items, nt, swz, stream);
   }
   return fail(QSIM_ERR_INVALID, "internal: bad member count %d", p.nm);
 }
@@ -273,21 +507,25 @@ static int gate_2q(const Group& g, int qa, int qb, const double* U, hipStream_t 
                          U[2 * 13], U[2 * 13 + 1], U[2 * 15], U[2 * 15 + 1]};
     rc = make_plan(g, &qa, 1, &qb, 1, V, &p);
   } else if (swap) {
-    // exchange |01> <-> |10>: a 2-member work item whose members are (a=0,b=1), (a=1,b=0)
-    Plan q;
-    const int t[2] = {qa, qb};
-    static const double I4[32] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0,
-                                  0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0};
-    rc = make_plan(g, t, 2, nullptr, 0, I4, &q);
-    if (rc) return rc;
+    // exchange |01> <-> |10>: 2-member work items (a=0,b=1) and (a=1,b=0), half the state.
+    static const double X2[8] = {0, 0, 1, 0, 1, 0, 0, 0};
+    // removed = {qa, qb}; member0 = |a=0,b=1>, member1 = |a=1,b=0>
+    int removed[2];
+    int nr = 0;
+    if (qa < g.k) removed[nr++] = qa;
+    if (qb < g.k) removed[nr++] = qb;
+    std::sort(removed, removed + nr);
     p.nm = 2;
-    p.member[0] = q.member[1];
-    p.member[1] = q.member[2];
-    p.count = q.count;
-    p.npos = q.npos;
-    for (int i = 0; i < 3; ++i) p.pos[i] = q.pos[i];
-    p.u[0] = make_double2(0, 0); p.u[1] = make_double2(1, 0);
-    p.u[2] = make_double2(1, 0); p.u[3] = make_double2(0, 0);
+    p.nsh = 0;
+    p.lane_bit[0] = p.lane_bit[1] = 0;
+    p.npos = nr;
+    for (int i = 0; i < 3; ++i) p.pos[i] = i < nr ? removed[i] : 0;
+    p.low_removed = nr ? removed[0] : 64;
+    p.high_removed = nr ? removed[nr - 1] : -1;
+    p.count = 1ull << (g.k - nr);
+    p.member[0] = resolve(g, 1ull << qb);
+    p.member[1] = resolve(g, 1ull << qa);
+    for (int i = 0; i < 4; ++i) p.u[i] = make_double2(X2[2 * i], X2[2 * i + 1]);
     rc = QSIM_OK;
   } else {
     const int t[2] = {qa, qb};

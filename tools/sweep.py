@@ -28,6 +28,7 @@ def timed(dev, fn, reps):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    only = set(sys.argv[3].split(",")) if len(sys.argv) > 3 else None
     dev = DeviceChunk.empty(n)
     dev.init_random(30)
     N = 1 << n
@@ -36,19 +37,20 @@ def main():
     z = rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4))
     U2, _ = np.linalg.qr(z)
     rows = []
-    for q in range(n):
+    want = lambda name: only is None or name in only
+    for q in range(n if want("H") else 0):
         med, mn = timed(dev, lambda: dev.apply_1q(q, H), reps)
         rows.append(("H", q, med, mn, 32 * N))
-    for q in range(n):
+    for q in range(n if want("T") else 0):
         med, mn = timed(dev, lambda: dev.apply_1q(q, T), reps)
         rows.append(("T", q, med, mn, 16 * N))
-    for q in range(1, n):
+    for q in range(1, n if want("CX(0,q)") else 0):
         med, mn = timed(dev, lambda: dev.apply_2q(0, q, CX), reps)
         rows.append(("CX(0,q)", q, med, mn, 16 * N))
-    for q in range(0, n - 1):
+    for q in range(0, n - 1 if want("CX(q,q+1)") else 0):
         med, mn = timed(dev, lambda: dev.apply_2q(q, q + 1, CX), reps)
         rows.append(("CX(q,q+1)", q, med, mn, 16 * N))
-    for q in range(0, n - 1, 3):
+    for q in range(0, n - 1 if want("U4(q+1,q)") else 0, 3):
         med, mn = timed(dev, lambda: dev.apply_2q(q + 1, q, U2), reps)
         rows.append(("U4(q+1,q)", q, med, mn, 32 * N))
     print(f"n={n} reps={reps} norm2={dev.norm2():.15f}")
@@ -57,6 +59,8 @@ def main():
         gbs = nbytes / (med * 1e-3) / 1e9
         print(f"{name:<10} {q:>3} {med:9.3f} {mn:9.3f} {gbs:9.1f} {gbs * 1e9 / PEAK:7.3f}")
     for name in ("H", "T", "CX(0,q)", "CX(q,q+1)", "U4(q+1,q)"):
+        if not any(r[0] == name for r in rows):
+            continue
         fr = [nb / (m * 1e-3) / PEAK for nm, _, m, _, nb in rows if nm == name]
         print(f"summary {name:<10} min frac {min(fr):.3f} median {np.median(fr):.3f} max {max(fr):.3f}")
 
