@@ -100,6 +100,21 @@ int qsim_max_abs_err_closed_form(qsim_chunk* c, int kind, int n_total_qubits,
 int qsim_time_begin(qsim_chunk* c);                        /* hipEventRecord on stream  */
 int qsim_time_end(qsim_chunk* c, float* elapsed_ms);       /* record + synchronize      */
 
+
+/* ---- per-launch timing for roofline reports (bench.py) ------------------------------- */
+/* Between begin and end every gate kernel launched on c's stream is bracketed by HIP events
+ * (no synchronisation, no extra kernels).  qsim_profile_end synchronises the stream and
+ * returns, per kernel class, the launch count, the summed event time and the summed
+ * algorithmic bytes (32 B per amplitude a launch reads and writes).           */
+typedef struct {
+  char kernel[48];
+  uint64_t launches;
+  double total_ms;
+  double algorithmic_bytes;
+} qsim_profile_entry;
+int qsim_profile_begin(qsim_chunk* c);
+int qsim_profile_end(qsim_chunk* c, int max_entries, int* n_entries, qsim_profile_entry* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,7 +62,14 @@ SIGNATURES = {
                                                C.POINTER(C.c_double)]),
     "qsim_time_begin": (C.c_int, [_P]),
     "qsim_time_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "qsim_profile_begin": (C.c_int, [_P]),
+    "qsim_profile_end": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), _P]),
 }
+
+
+class ProfileEntry(C.Structure):
+    _fields_ = [("kernel", C.c_char * 48), ("launches", C.c_uint64),
+                ("total_ms", C.c_double), ("algorithmic_bytes", C.c_double)]
 
 _lib = None
 

@@ -316,6 +316,57 @@ static const Tuning& tuning() {
   return t;
 }
 
+// ---- per-launch HIP-event timing (bench.py roofline): events are recorded on the launch
+// stream around every gate kernel while a profile is open; nothing is synchronised until
+// qsim_profile_end.
+struct LaunchRecord {
+  int cls;            // kernel class id
+  double bytes;       // algorithmic bytes: 32 B per amplitude touched
+  hipEvent_t e0, e1;
+};
+struct ProfileState {
+  bool open = false;
+  hipStream_t stream = nullptr;
+  std::vector<LaunchRecord> records;
+  std::vector<hipEvent_t> pool;  // recycled events
+};
+static ProfileState g_prof;
+static const char* const kClassNames[] = {
+    "k_gate<1> scale (diagonal subset)", "k_gate<2> 2x2 butterfly", "k_gate<4> 4x4 butterfly",
+    "k_gate_shuffle<1,1> lane 1q", "k_gate_shuffle<1,2> lane 2q", "k_gate_shuffle<2,1> lane+reg 2q",
+    "k_tile fused pass"};
+constexpr int kNumClasses = 7;
+
+static hipEvent_t prof_event() {
+  if (!g_prof.pool.empty()) {
+    hipEvent_t e = g_prof.pool.back();
+    g_prof.pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct ProfileScope {  // RAII around one launch
+  bool on;
+  LaunchRecord rec;
+  ProfileScope(int cls, double bytes, hipStream_t stream) {
+    on = g_prof.open && g_prof.stream == stream;
+    if (!on) return;
+    rec.cls = cls;
+    rec.bytes = bytes;
+    rec.e0 = prof_event();
+    rec.e1 = prof_event();
+    (void)hipEventRecord(rec.e0, stream);
+  }
+  void done(hipStream_t stream) {
+    if (!on) return;
+    (void)hipEventRecord(rec.e1, stream);
+    g_prof.records.push_back(rec);
+  }
+};
+
 // Resolve a virtual offset (bits >= k select the chunk) to a device pointer.
 static double2* resolve(const Group& g, u64 voff) {
   const u64 ci = voff >> g.k;
@@ -392,7 +443,9 @@ static int launch_reg(const Plan& p, hipStream_t stream) {
   for (int i = 0; i < NM * NM; ++i) a.u[i] = p.u[i];
   const u64 per_block = (u64)kBlock * ITEMS;
   const u64 blocks = (p.count + per_block - 1) / per_block;
+  ProfileScope prof(NM == 1 ? 0 : (NM == 2 ? 1 : 2), 32.0 * NM * (double)p.count, stream);
   hipLaunchKernelGGL((k_gate<NM, ITEMS, NT, SWZ>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, a);
+  prof.done(stream);
   HIP_TRY(hipGetLastError());
   return QSIM_OK;
 }
@@ -410,7 +463,9 @@ static int launch_shuffle(const Plan& p, hipStream_t stream) {
   for (int i = 0; i < DIM * DIM; ++i) a.u[i] = p.u[i];
   const u64 per_block = (u64)kBlock * ITEMS;
   const u64 blocks = (p.count + per_block - 1) / per_block;
+  ProfileScope prof(NMR == 2 ? 5 : (NSH == 1 ? 3 : 4), 32.0 * NMR * (double)p.count, stream);
   hipLaunchKernelGGL((k_gate_shuffle<NMR, NSH, ITEMS, NT>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, a);
+  prof.done(stream);
   HIP_TRY(hipGetLastError());
   return QSIM_OK;
 }
@@ -1017,6 +1072,52 @@ int qsim_time_end(qsim_chunk* c, float* elapsed_ms) {
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   HIP_TRY(hipEventSynchronize(c->ev1));
   HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+  return QSIM_OK;
+}
+
+int qsim_profile_begin(qsim_chunk* c) {
+  int rc = check_chunk(c, "qsim_profile_begin");
+  if (rc) return rc;
+  if (g_prof.open) return fail(QSIM_ERR_INVALID, "a profile is already open");
+  HIP_TRY(hipSetDevice(c->device));
+  g_prof.records.clear();
+  g_prof.stream = c->stream;
+  g_prof.open = true;
+  return QSIM_OK;
+}
+
+int qsim_profile_end(qsim_chunk* c, int max_entries, int* n_entries, qsim_profile_entry* out) {
+  int rc = check_chunk(c, "qsim_profile_end");
+  if (rc) return rc;
+  if (!g_prof.open) return fail(QSIM_ERR_INVALID, "no profile is open");
+  if (!n_entries || (!out && max_entries > 0)) return fail(QSIM_ERR_INVALID, "null output");
+  g_prof.open = false;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  uint64_t launches[kNumClasses] = {0};
+  double ms[kNumClasses] = {0}, bytes[kNumClasses] = {0};
+  for (LaunchRecord& r : g_prof.records) {
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, r.e0, r.e1));
+    launches[r.cls] += 1;
+    ms[r.cls] += t;
+    bytes[r.cls] += r.bytes;
+    g_prof.pool.push_back(r.e0);
+    g_prof.pool.push_back(r.e1);
+  }
+  g_prof.records.clear();
+  int n = 0;
+  for (int cls = 0; cls < kNumClasses; ++cls) {
+    if (!launches[cls]) continue;
+    if (n < max_entries) {
+      std::snprintf(out[n].kernel, sizeof out[n].kernel, "%s", kClassNames[cls]);
+      out[n].launches = launches[cls];
+      out[n].total_ms = ms[cls];
+      out[n].algorithmic_bytes = bytes[cls];
+    }
+    ++n;
+  }
+  *n_entries = n;
   return QSIM_OK;
 }
 

@@ -161,6 +161,20 @@ class DeviceChunk:
         _lib.check(_lib.load().qsim_time_end(self._h, C.byref(ms)))
         return ms.value
 
+    def profile_begin(self) -> None:
+        """Bracket every gate launch on this chunk's stream with HIP events until profile_end."""
+        _lib.check(_lib.load().qsim_profile_begin(self._h))
+
+    def profile_end(self) -> list[dict]:
+        entries = (_lib.ProfileEntry * 16)()
+        n = C.c_int()
+        _lib.check(_lib.load().qsim_profile_end(self._h, 16, C.byref(n), C.cast(entries, C.c_void_p)))
+        out = []
+        for e in entries[: min(n.value, 16)]:
+            out.append({"kernel": e.kernel.decode(), "launches": int(e.launches),
+                        "total_ms": float(e.total_ms), "algorithmic_bytes": float(e.algorithmic_bytes)})
+        return out
+
     def pack_half(self, bit: int, value: int, buf: "DeviceChunk") -> None:
         _lib.check(_lib.load().qsim_pack_half(self._h, bit, value, buf._h))
 
