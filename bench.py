@@ -144,7 +144,7 @@ def main():
 
     engine = make_engine(n, world, rank, local_rank, mode=args.mode)
     engine.init_zero_state()
-    plan = engine.plan(circuit)
+    plan = engine.plan(circuit, repeats=args.warmup + args.steps)
 
     for _ in range(args.warmup):
         engine.execute(plan)

@@ -88,6 +88,14 @@ int qsim_apply_2q_quad(qsim_chunk* c00, qsim_chunk* c01, qsim_chunk* c10, qsim_c
  * ascending order (pack), and the inverse scatter (unpack).  `buf` holds k-1 qubits.   */
 int qsim_pack_half(const qsim_chunk* src, int bit, int value, qsim_chunk* buf);
 int qsim_unpack_half(qsim_chunk* dst, int bit, int value, const qsim_chunk* buf);
+/* Slab form for the all-to-all re-layout that replaces a staging SWAP list
+ * (wenbo_engine/circuit/staging.py:136-152): the 2^(k-m) amplitudes of `src` whose index bits
+ * bits[0..m) equal the bits of `pattern` (bit i of pattern <-> bits[i]), ascending, to/from
+ * buf[buf_offset_amps ...).  1 <= m <= 3.                                               */
+int qsim_pack_bits(const qsim_chunk* src, int m, const int32_t* bits, int pattern,
+                   qsim_chunk* buf, uint64_t buf_offset_amps);
+int qsim_unpack_bits(qsim_chunk* dst, int m, const int32_t* bits, int pattern,
+                     const qsim_chunk* buf, uint64_t buf_offset_amps);
 
 /* ---- synchronisation, reductions, timing ------------------------------------------- */
 int qsim_sync(qsim_chunk* c);

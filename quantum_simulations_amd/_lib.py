@@ -56,6 +56,8 @@ SIGNATURES = {
     "qsim_apply_2q_quad": (C.c_int, [_P, _P, _P, _P, _P]),
     "qsim_pack_half": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "qsim_unpack_half": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "qsim_pack_bits": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_uint64]),
+    "qsim_unpack_bits": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_uint64]),
     "qsim_sync": (C.c_int, [_P]),
     "qsim_norm2": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "qsim_max_abs_err_closed_form": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64,

@@ -153,8 +153,19 @@ def _compute_local_qubits_heuristic(gates: list[dict], n: int, k: int) -> list[s
     return stages
 
 
-def _local_sets_to_steps(gates, n: int, k: int, local_sets) -> tuple[list[dict], list[int]]:
-    """Stage sets -> steps: [SWAP step] [fused local step] [insular-global step] per stage."""
+def _local_sets_to_steps(gates, n: int, k: int, local_sets,
+                         strict_order: bool = False) -> tuple[list[dict], list[int]]:
+    """Stage sets -> steps: [SWAP step] [fused local step] [insular-global step] per stage.
+
+    Reference behaviour (`strict_order=False`, staging.py:447-519): ALL of a stage's local
+    gates are emitted before ALL of its insular-global ops.  That reorders a diagonal gate
+    with a global qubit past a later non-diagonal gate on its other qubit (e.g. CR(5,1)
+    then H(1) in one stage) -- a defect of the reference: `generate_w_qft(6)`, k=3,
+    heuristic gives max |amp error| 0.32 against its own ref_dense (tests/test_planner_golden.py
+    pins this).  `strict_order=True` keeps the same stages and SWAPs but closes the
+    local/global step pair whenever a local gate shares a qubit with a pending global op, so
+    every pair of gates on a common qubit keeps its circuit order; the runners of this build
+    always plan with strict_order=True."""
     qmap = QubitMap(n)
     steps: list[dict] = []
     done = [False] * len(gates)
@@ -165,17 +176,27 @@ def _local_sets_to_steps(gates, n: int, k: int, local_sets) -> tuple[list[dict],
         is_local = [q in want for q in range(n)]
         stage_local: list[dict] = []
         stage_global: list[tuple] = []
+        global_qubits: set[int] = set()
+
+        def close_pair() -> None:
+            steps.extend(_fused_local_step(stage_local, qmap))
+            if stage_global:
+                steps.append({"local_ops": [], "nonlocal_ops": list(stage_global)})
+            stage_local.clear()
+            stage_global.clear()
+            global_qubits.clear()
 
         def place(gate: dict) -> None:
             if all(qmap.phys(q) < k for q in gate["qubits"]):
+                if strict_order and not global_qubits.isdisjoint(gate["qubits"]):
+                    close_pair()
                 stage_local.append(gate)
             else:  # only insular qubits are global
                 stage_global.append(_as_physical_op(gate, qmap))
+                global_qubits.update(gate["qubits"])
 
         _sweep_executable(gates, done, is_local, on_run=place)
-        steps.extend(_fused_local_step(stage_local, qmap))
-        if stage_global:
-            steps.append({"local_ops": [], "nonlocal_ops": stage_global})
+        close_pair()
     return steps, qmap.to_list()
 
 
@@ -218,8 +239,9 @@ def _greedy_stages(gates: list[dict], n: int, k: int, lookahead: int):
 
 # ------------------------------------------------------------------- entry points
 def atlas_stages(circuit_dict: dict, k: int, method: str = "heuristic",
-                 lookahead: int = 200) -> tuple[list[dict], list[int]]:
-    """Circuit -> (steps, log_to_phys).  `k` = log2(shard amplitudes)."""
+                 lookahead: int = 200, strict_order: bool = False) -> tuple[list[dict], list[int]]:
+    """Circuit -> (steps, log_to_phys).  `k` = log2(shard amplitudes).  `strict_order` (this
+    build's addition, see `_local_sets_to_steps`) only affects method="heuristic"."""
     cd = validate_circuit_dict(circuit_dict)
     n = cd["number_of_qubits"]
     gates = cd["gates"]
@@ -234,7 +256,8 @@ def atlas_stages(circuit_dict: dict, k: int, method: str = "heuristic",
                                   "(SURVEY 2 row 2); use 'heuristic' or 'greedy'")
     if method != "heuristic":
         raise ValueError(f"unknown staging method: {method!r}")
-    return _local_sets_to_steps(gates, n, k, _compute_local_qubits_heuristic(gates, n, k))
+    return _local_sets_to_steps(gates, n, k, _compute_local_qubits_heuristic(gates, n, k),
+                                strict_order=strict_order)
 
 
 def permute_state(state: np.ndarray, log_to_phys: list[int]) -> np.ndarray:

@@ -673,6 +673,21 @@ __global__ void k_unpack_half(double2* __restrict__ dst, const double2* __restri
   }
 }
 
+// slab gather / scatter for the all-to-all re-layout: j runs over the 2^(k-m) amplitudes whose
+// bits `pos` equal the pattern folded into value_off
+__global__ void k_pack_bits(double2* __restrict__ dst, const double2* __restrict__ src, u64 n_slab,
+                            int npos, int p0, int p1, int p2, u64 value_off) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n_slab; j += stride)
+    dst[j] = ld_amp<true>(src + (expand_index(j, npos, p0, p1, p2) | value_off));
+}
+__global__ void k_unpack_bits(double2* __restrict__ dst, const double2* __restrict__ src, u64 n_slab,
+                              int npos, int p0, int p1, int p2, u64 value_off) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n_slab; j += stride)
+    dst[expand_index(j, npos, p0, p1, p2) | value_off] = ld_amp<true>(src + j);
+}
+
 constexpr int kReduceBlocks = 2048;
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -1016,6 +1031,56 @@ int qsim_unpack_half(qsim_chunk* dst, int bit, int value, const qsim_chunk* buf)
   const u64 n_half = amps(buf);
   hipLaunchKernelGGL(k_unpack_half, dim3(stream_grid(n_half)), dim3(kBlock), 0, dst->stream,
                      dst->amp, (const double2*)buf->amp, n_half, bit, value ? (1ull << bit) : 0ull);
+  HIP_TRY(hipGetLastError());
+  return QSIM_OK;
+}
+
+static int slab_args(const qsim_chunk* c, int m, const int32_t* bits, int pattern, const qsim_chunk* buf,
+                     uint64_t buf_offset, int pos[3], u64* value_off, u64* n_slab) {
+  if (m < 1 || m > 3 || !bits) return fail(QSIM_ERR_INVALID, "slab: 1..3 bits expected, got %d", m);
+  if (m > c->k) return fail(QSIM_ERR_INVALID, "slab: more bits than the chunk has");
+  if (pattern < 0 || pattern >= (1 << m)) return fail(QSIM_ERR_INVALID, "slab: pattern out of range");
+  int sorted[3] = {0, 0, 0};
+  *value_off = 0;
+  for (int i = 0; i < m; ++i) {
+    if (bits[i] < 0 || bits[i] >= c->k) return fail(QSIM_ERR_INVALID, "slab: bit %d out of range", bits[i]);
+    for (int j = 0; j < i; ++j)
+      if (bits[j] == bits[i]) return fail(QSIM_ERR_INVALID, "slab: repeated bit %d", bits[i]);
+    sorted[i] = bits[i];
+    if ((pattern >> i) & 1) *value_off |= 1ull << bits[i];
+  }
+  std::sort(sorted, sorted + m);
+  for (int i = 0; i < 3; ++i) pos[i] = sorted[i];
+  *n_slab = 1ull << (c->k - m);
+  if (buf_offset > amps(buf) || *n_slab > amps(buf) - buf_offset)
+    return fail(QSIM_ERR_INVALID, "slab: buffer range outside the buffer chunk");
+  return QSIM_OK;
+}
+
+int qsim_pack_bits(const qsim_chunk* src, int m, const int32_t* bits, int pattern, qsim_chunk* buf,
+                   uint64_t buf_offset_amps) {
+  int rc = check_chunk(src, "qsim_pack_bits");
+  if (rc || (rc = check_chunk(buf, "qsim_pack_bits"))) return rc;
+  int pos[3];
+  u64 voff, n_slab;
+  if ((rc = slab_args(src, m, bits, pattern, buf, buf_offset_amps, pos, &voff, &n_slab))) return rc;
+  HIP_TRY(hipSetDevice(src->device));
+  hipLaunchKernelGGL(k_pack_bits, dim3(stream_grid(n_slab)), dim3(kBlock), 0, src->stream,
+                     buf->amp + buf_offset_amps, (const double2*)src->amp, n_slab, m, pos[0], pos[1], pos[2], voff);
+  HIP_TRY(hipGetLastError());
+  return QSIM_OK;
+}
+
+int qsim_unpack_bits(qsim_chunk* dst, int m, const int32_t* bits, int pattern, const qsim_chunk* buf,
+                     uint64_t buf_offset_amps) {
+  int rc = check_chunk(dst, "qsim_unpack_bits");
+  if (rc || (rc = check_chunk(buf, "qsim_unpack_bits"))) return rc;
+  int pos[3];
+  u64 voff, n_slab;
+  if ((rc = slab_args(dst, m, bits, pattern, buf, buf_offset_amps, pos, &voff, &n_slab))) return rc;
+  HIP_TRY(hipSetDevice(dst->device));
+  hipLaunchKernelGGL(k_unpack_bits, dim3(stream_grid(n_slab)), dim3(kBlock), 0, dst->stream,
+                     dst->amp, (const double2*)buf->amp + buf_offset_amps, n_slab, m, pos[0], pos[1], pos[2], voff);
   HIP_TRY(hipGetLastError());
   return QSIM_OK;
 }

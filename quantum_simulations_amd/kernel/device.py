@@ -182,6 +182,17 @@ class DeviceChunk:
         _lib.check(_lib.load().qsim_unpack_half(self._h, bit, value, buf._h))
 
 
+    def pack_bits(self, bits, pattern: int, buf: "DeviceChunk", buf_offset: int = 0) -> None:
+        b = np.asarray(bits, dtype=np.int32)
+        _lib.check(_lib.load().qsim_pack_bits(self._h, len(b), b.ctypes.data_as(C.c_void_p), int(pattern),
+                                              buf._h, int(buf_offset)))
+
+    def unpack_bits(self, bits, pattern: int, buf: "DeviceChunk", buf_offset: int = 0) -> None:
+        b = np.asarray(bits, dtype=np.int32)
+        _lib.check(_lib.load().qsim_unpack_bits(self._h, len(b), b.ctypes.data_as(C.c_void_p), int(pattern),
+                                                buf._h, int(buf_offset)))
+
+
 def device_count() -> int:
     n = C.c_int()
     _lib.check(_lib.load().qsim_device_count(C.byref(n)))

@@ -49,8 +49,9 @@ class SingleGpuEngine:
         return self.state.download()
 
     # ---- planning / execution --------------------------------------------------------
-    def plan(self, circuit_dict: dict) -> list:
-        """Plan = list of passes, each a list of (qubits, U) handed to ONE C call."""
+    def plan(self, circuit_dict: dict, repeats: int = 1) -> list:
+        """Plan = list of passes, each a list of (qubits, U) handed to ONE C call (the same
+        plan serves every repeat: the single-GPU layout never changes)."""
         cd = validate_circuit_dict(circuit_dict)
         if cd["number_of_qubits"] != self.n:
             raise ValueError(f"circuit has {cd['number_of_qubits']} qubits, engine has {self.n}")

@@ -1,0 +1,169 @@
+"""Single-GPU chunked runner with the reference's `run` / `collect_state` interface.
+
+Mirrors wenbo_engine/runner/single_node.py:78-346.  The 2^n state is ONE HBM allocation;
+"chunk c" is the window [c*2^k, (c+1)*2^k) of it (block_store.py:14-15), so the reference's
+structure -- per step: partner groups first (local ops on the group's chunks, then the
+non-local butterflies `apply_1q_pair / apply_2q_pair_* / apply_2q_quad`), then the remaining
+chunks -- runs unchanged, minus everything that existed only because chunks lived on disk
+(double-buffer directories, fsync, manifest, WAL, fencing: SURVEY 2 rows 4-5, out of scope).
+
+`run()` returns an `HbmStateBuffer` (the reference returns the path of the committed buffer
+directory); `collect_state()` accepts it and yields the complex128 vector, undoing the staging
+permutation when asked, exactly like the reference (single_node.py:326-346).
+"""
+from __future__ import annotations
+
+import json
+import math
+from pathlib import Path
+
+import numpy as np
+
+from quantum_simulations_amd.circuit.fusion import batch_levels, split_by_locality
+from quantum_simulations_amd.circuit.io import levelize, validate_circuit_dict
+from quantum_simulations_amd.circuit.staging import atlas_stages, permute_state
+from quantum_simulations_amd.kernel import gpu_nonlocal
+from quantum_simulations_amd.kernel.device import DeviceChunk
+
+KERNELS = ("hip", "scalar", "batched")  # the reference's names select the same HIP module here
+
+
+class HbmStateBuffer:
+    """Final state of a run: the HBM allocation + its chunk windows."""
+
+    def __init__(self, state: DeviceChunk, chunks: list[DeviceChunk], n_qubits: int,
+                 chunk_size: int, work_dir: Path | None):
+        self.state, self.chunks = state, chunks
+        self.n_qubits, self.chunk_size, self.work_dir = n_qubits, chunk_size, work_dir
+
+    def close(self) -> None:
+        for c in self.chunks:
+            c.close()
+        self.chunks = []
+        self.state.close()
+
+
+def build_steps(cd: dict, k: int, use_fusion: bool, use_staging: bool, staging_method: str):
+    """Planner selection of single_node.run (single_node.py:108-121)."""
+    if use_staging:  # strict_order: see staging._local_sets_to_steps (reference defect)
+        return atlas_stages(cd, k, method=staging_method, strict_order=True)
+    levels = levelize(cd)
+    if use_fusion:
+        return batch_levels(levels, k), None
+    steps = []
+    for gates in levels:
+        if gates:
+            local, nonlocal_ = split_by_locality(gates, k)
+            steps.append({"local_ops": local, "nonlocal_ops": nonlocal_})
+    return steps, None
+
+
+def run(circuit_dict: dict, work_dir: str | Path | None = None, chunk_size: int = 1 << 20,
+        kernel: str = "hip", use_wal: bool = True, use_fencing: bool = False,
+        use_fusion: bool = False, use_staging: bool = False,
+        staging_method: str = "heuristic", device: int = 0) -> HbmStateBuffer:
+    """Run the full circuit on HBM-resident chunks.  `use_wal` / `use_fencing` are accepted for
+    signature compatibility and ignored (no on-disk buffers to protect)."""
+    cd = validate_circuit_dict(circuit_dict)
+    n = cd["number_of_qubits"]
+    N = 1 << n
+    chunk_size = min(chunk_size, N)
+    if N % chunk_size != 0:
+        raise ValueError("2^n must be divisible by chunk_size")
+    if kernel not in KERNELS:
+        raise ValueError(f"unknown kernel {kernel!r}; this build runs HIP kernels only")
+    k = int(math.log2(chunk_size))
+    steps, log_to_phys = build_steps(cd, k, use_fusion, use_staging, staging_method)
+
+    state = DeviceChunk.zero_state(n, device)  # |0..0>: chunk 0, element 0 = 1 (block_store.py:35-65)
+    n_chunks = N // chunk_size
+    chunks = [state.view(c * chunk_size, k) for c in range(n_chunks)] if n_chunks > 1 else [state]
+    for step in steps:
+        _apply_step(state, chunks, step["local_ops"], step["nonlocal_ops"], k)
+
+    work = Path(work_dir) if work_dir is not None else None
+    if work is not None and log_to_phys and log_to_phys != list(range(n)):
+        work.mkdir(parents=True, exist_ok=True)
+        with open(work / "qubit_mapping.json", "w") as f:  # single_node.py:129-134
+            json.dump(log_to_phys, f)
+    buf = HbmStateBuffer(state, chunks if n_chunks > 1 else [], n, chunk_size, work)
+    buf.log_to_phys = log_to_phys
+    return buf
+
+
+def _apply_step(state: DeviceChunk, chunks: list[DeviceChunk], local_ops, nonlocal_ops, k: int) -> None:
+    """One step.  Local ops use bits < k only, so "every chunk gets the same local pass"
+    (_process_local_chunk, single_node.py:208-216) is one launch per op over the whole
+    allocation; each chunk still sees local ops before its non-local ones (:253-262)."""
+    if local_ops:
+        state.apply_ops(local_ops)
+    if nonlocal_ops:
+        _process_nonlocal_groups(chunks, nonlocal_ops, k)
+
+
+def _process_nonlocal_groups(chunks, nonlocal_ops, k: int) -> None:
+    """Partner groups = chunk indices that agree outside the step's non-local bits
+    (single_node.py:219-268)."""
+    bits = sorted({q - k for qs, _ in nonlocal_ops for q in qs if q >= k})
+    mask = sum(1 << b for b in bits)
+    seen: set[int] = set()
+    for c in range(len(chunks)):
+        base = c & ~mask
+        if base in seen:
+            continue
+        seen.add(base)
+        group = {}
+        for combo in range(1 << len(bits)):
+            idx = base
+            for i, b in enumerate(bits):
+                if combo >> i & 1:
+                    idx |= 1 << b
+            group[idx] = chunks[idx]
+        for qs, U in nonlocal_ops:
+            _apply_nonlocal(group, qs, U, k)
+
+
+def _apply_nonlocal(data: dict, qs: list[int], U: np.ndarray, k: int) -> None:
+    """Dispatch of one non-local gate inside a loaded group (single_node.py:271-321)."""
+    def pairs(pbit: int):
+        done = set()
+        for ci in data:
+            c0 = ci & ~(1 << pbit)
+            if c0 not in done:
+                done.add(c0)
+                yield data[c0], data[c0 | (1 << pbit)]
+
+    if len(qs) == 1:
+        for c0, c1 in pairs(qs[0] - k):
+            gpu_nonlocal.apply_1q_pair(c0, c1, U)
+        return
+    qa, qb = qs
+    if qa < k:
+        for c0, c1 in pairs(qb - k):
+            gpu_nonlocal.apply_2q_pair_qa_local(c0, c1, qa, U)
+    elif qb < k:
+        for c0, c1 in pairs(qa - k):
+            gpu_nonlocal.apply_2q_pair_qb_local(c0, c1, qb, U)
+    else:
+        pa, pb = qa - k, qb - k
+        done = set()
+        for ci in data:
+            cb = ci & ~(1 << pa) & ~(1 << pb)
+            if cb in done:
+                continue
+            done.add(cb)
+            gpu_nonlocal.apply_2q_quad(data[cb], data[cb | (1 << pb)], data[cb | (1 << pa)],
+                                       data[cb | (1 << pa) | (1 << pb)], U)
+
+
+def collect_state(buf: HbmStateBuffer, apply_permutation: bool = False,
+                  work_dir: str | Path | None = None) -> np.ndarray:
+    """All chunks back as one complex128 vector; with `apply_permutation` and a
+    `qubit_mapping.json` in `work_dir` the staging permutation is undone."""
+    state = buf.state.download()
+    if apply_permutation and work_dir is not None:
+        mapping = Path(work_dir) / "qubit_mapping.json"
+        if mapping.exists():
+            with open(mapping) as f:
+                state = permute_state(state, json.load(f))
+    return state

@@ -1,0 +1,72 @@
+"""TEST DOUBLE: a numpy shard backend for `DistributedEngine`, built on the oracle, so the
+communication schedule (exchange / re-layout / rank-bit phases) can be exercised with gloo on
+CPU-only machines.  It lives under tests/ and is never selected by the product."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import dense_oracle as orc
+
+
+class CpuShardBackend:
+    def __init__(self, k: int):
+        self.k = k
+        self._t: dict[str, torch.Tensor] = {}
+        self.tensor("state")
+
+    def tensor(self, name: str) -> torch.Tensor:
+        if name not in self._t:
+            self._t[name] = torch.zeros(2 << self.k, dtype=torch.float64)
+        return self._t[name]
+
+    def _c(self, name: str) -> np.ndarray:
+        return self.tensor(name).numpy().view(np.complex128)
+
+    def init_zero(self, set_amp0: bool) -> None:
+        v = self._c("state")
+        v[:] = 0
+        if set_amp0:
+            v[0] = 1.0
+
+    def norm2(self) -> float:
+        return float(np.vdot(self._c("state"), self._c("state")).real)
+
+    def download(self) -> np.ndarray:
+        return self._c("state").copy()
+
+    def sync(self) -> None:
+        pass
+
+    def apply_ops(self, ops) -> None:
+        orc.apply_ops(self._c("state"), ops)
+
+    def apply_1q_pair(self, names, U) -> None:
+        orc.apply_1q_pair(self._c(names[0]), self._c(names[1]), U)
+
+    def apply_2q_pair_qa_local(self, names, qa, U) -> None:
+        orc.apply_2q_pair_qa_local(self._c(names[0]), self._c(names[1]), qa, U)
+
+    def apply_2q_pair_qb_local(self, names, qb, U) -> None:
+        orc.apply_2q_pair_qb_local(self._c(names[0]), self._c(names[1]), qb, U)
+
+    def apply_2q_quad(self, names, U) -> None:
+        orc.apply_2q_quad(*(self._c(n) for n in names), U)
+
+    def _slab_index(self, bits, pattern: int) -> np.ndarray:
+        idx = np.arange(1 << self.k, dtype=np.int64)
+        keep = np.ones(idx.shape, dtype=bool)
+        for i, b in enumerate(bits):
+            keep &= ((idx >> b) & 1) == ((pattern >> i) & 1)
+        return idx[keep]
+
+    def pack_bits(self, bits, pattern: int, dst: str, dst_offset: int) -> None:
+        sel = self._slab_index(bits, pattern)
+        self._c(dst)[dst_offset:dst_offset + sel.size] = self._c("state")[sel]
+
+    def unpack_bits(self, bits, pattern: int, src: str, src_offset: int) -> None:
+        sel = self._slab_index(bits, pattern)
+        self._c("state")[sel] = self._c(src)[src_offset:src_offset + sel.size]
+
+    def close(self) -> None:
+        self._t.clear()

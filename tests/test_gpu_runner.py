@@ -1,0 +1,104 @@
+"""GPU tests of the callers of the hot path: chunked single-GPU runner (partner-chunk
+butterflies on HBM windows) and the v3-style driver, against the oracle (1e-10) and the
+reference's own chunked complex64 runs (tests/golden/chunked_c64.npz, 1e-6 as in
+wenbo_engine/tests/test_nonlocal.py)."""
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import dense_oracle as orc
+from tests.golden_io import circuit_from_json, golden_circuits, jdoc, npz
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def runner():
+    from quantum_simulations_amd.runner import single_node
+    return single_node
+
+
+def _check(runner, cd, chunk_size, want=None, atol=1e-10, **kw):
+    with tempfile.TemporaryDirectory() as td:
+        buf = runner.run(cd, td, chunk_size=chunk_size, **kw)
+        got = runner.collect_state(buf, apply_permutation=True, work_dir=td)
+        buf.close()
+    ref = orc.simulate(cd) if want is None else want
+    np.testing.assert_allclose(got, ref, rtol=0, atol=atol)
+    return got
+
+
+def test_reference_chunked_runs_c64(runner):
+    cases = jdoc("chunked_c64.json")
+    z = npz("chunked_c64.npz")
+    for name, meta in cases.items():
+        cd = circuit_from_json(meta["circuit"])
+        got = _check(runner, cd, meta["chunk_size"], **meta["kwargs"])
+        np.testing.assert_allclose(got, z[name], rtol=0, atol=1e-6, err_msg=name)
+
+
+NQ = 4
+NONLOCAL_CASES = {  # wenbo_engine/tests/test_nonlocal.py:28-193, every butterfly case
+    "h_q2": [([2], "H")], "x_q3": [([3], "X")],
+    "t_q2": [([0], "H"), ([2], "H"), ([2], "T")],
+    "cnot_q0_q2": [([0], "H"), ([0, 2], "CNOT")], "cnot_q1_q3": [([1], "H"), ([1, 3], "CNOT")],
+    "cz_q0_q3": [([0], "H"), ([3], "H"), ([0, 3], "CZ")], "swap_q1_q2": [([1], "X"), ([1, 2], "SWAP")],
+    "cnot_q2_q0": [([2], "H"), ([2, 0], "CNOT")], "cnot_q3_q1": [([3], "H"), ([3, 1], "CNOT")],
+    "cy_q2_q1": [([2], "H"), ([2, 1], "CY")],
+    "cnot_q2_q3": [([2], "H"), ([2, 3], "CNOT")], "swap_q2_q3": [([2], "X"), ([2, 3], "SWAP")],
+    "cz_q3_q2": [([2], "H"), ([3], "H"), ([3, 2], "CZ")],
+    "h_all": [([i], "H") for i in range(NQ)],
+    "mixed": [([0], "H"), ([2], "H"), ([0, 1], "CNOT"), ([2, 3], "CNOT")],
+}
+
+
+@pytest.mark.parametrize("name", sorted(NONLOCAL_CASES))
+@pytest.mark.parametrize("chunk_size", [1, 2, 4, 8])
+def test_nonlocal_cases(runner, name, chunk_size):
+    cd = {"number_of_qubits": NQ,
+          "gates": [{"qubits": q, "gate": g} for q, g in NONLOCAL_CASES[name]]}
+    _check(runner, cd, chunk_size)
+
+
+@pytest.mark.parametrize("kw", [{}, {"use_fusion": True}, {"use_staging": True},
+                                {"use_staging": True, "staging_method": "greedy"}])
+@pytest.mark.parametrize("cname,chunk_size", [("fx_ghz_6", 4), ("fx_qft_6", 8), ("fx_qft_4", 2),
+                                              ("v1_w_qft_6", 8), ("own_random_1q_cx_10", 64),
+                                              ("own_clifford_t_10", 32), ("v1_qpe_5", 16)])
+def test_full_circuits_chunked(runner, cname, chunk_size, kw):
+    _check(runner, golden_circuits()[cname], chunk_size, want=npz("states.npz")[cname], **kw)
+
+
+def test_runner_errors(runner):
+    with pytest.raises(ValueError, match="divisible by chunk_size"):
+        runner.run(golden_circuits()["fx_ghz_4"], None, chunk_size=3)
+    with pytest.raises(ValueError, match="unknown staging method"):
+        runner.run(golden_circuits()["fx_ghz_4"], None, chunk_size=4, use_staging=True,
+                   staging_method="bogus")
+    with pytest.raises(ValueError, match="unsupported gate"):
+        runner.run({"number_of_qubits": 2, "gates": [{"qubits": [0], "gate": "NOPE"}]}, None)
+
+
+def test_v3_style_driver():
+    from quantum_simulations_amd.driver import Driver
+    cd = golden_circuits()["v1_ghz_qft_6"]
+    want = npz("states.npz")["v1_ghz_qft_6"]
+    with Driver() as drv:
+        res = drv.run_circuit(cd)
+        seq = drv.run_circuit(cd, enable_parallel=False)
+        assert (res.n_qubits, res.n_gates) == (6, len(cd["gates"]))
+        assert sum(res.parallel_groups) == res.n_gates and res.n_levels == len(res.parallel_groups)
+        assert seq.parallel_groups == [1] * res.n_gates
+        psi = drv.get_state_vector(res)
+        np.testing.assert_allclose(psi, want, rtol=1e-10, atol=1e-10)  # v3/v1 parity bar
+        np.testing.assert_allclose(drv.get_state_vector(seq), psi, rtol=1e-10, atol=1e-10)
+        sparse = drv.get_state_dict(res)
+        assert all(abs(v.real) > 1e-15 or abs(v.imag) > 1e-15 for v in sparse.values())
+        dense = np.zeros(64, dtype=complex)
+        for i, v in sparse.items():
+            dense[i] = v
+        np.testing.assert_allclose(dense, want, atol=1e-10)
+    ghz = Driver().run_circuit(golden_circuits()["fx_ghz_5"])
+    d = Driver().get_state_dict(ghz)
+    assert sorted(d) == [0, 31] and abs(d[0] - 2 ** -0.5) < 1e-12

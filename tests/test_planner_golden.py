@@ -186,3 +186,46 @@ def test_staging_misc():
         staging.atlas_stages(gen.generate_qft_circuit(4), 2, method="ilp")
     st = staging.staging_stats(gen.generate_qft_circuit(6), 3)
     assert {"baseline_steps", "staged_steps", "reduction"} <= set(st)
+
+
+# ------------------------------------------------------------------ reference defect, pinned
+def test_reference_heuristic_staging_reorders_dependent_gates():
+    """`generate_w_qft(6)`, k=3, heuristic: the reference emits a stage's local gates before
+    its insular-global ops and so moves H(q) in front of an earlier CR(.., q).  Executed in
+    emitted order (oracle, whole state as one chunk) the reference's own step list is wrong by
+    0.32; with strict_order=True the same stages give the exact state."""
+    from oracle import dense_oracle as orc
+    cd = gen.generate_w_qft(6)
+    want = orc.simulate(validate_circuit_dict(cd))
+
+    def run_steps(steps, l2p):
+        psi = np.zeros(64, dtype=np.complex128)
+        psi[0] = 1.0
+        for st in steps:
+            orc.apply_ops(psi, st["local_ops"])
+            orc.apply_ops(psi, st["nonlocal_ops"])
+        return orc.permute_state(psi, l2p)
+
+    ref_steps, ref_l2p = staging.atlas_stages(cd, 3, method="heuristic")
+    _same_steps(ref_steps, PLAN["atlas"]["w_qft_6|k=3|heuristic"]["steps"])  # == the reference
+    assert np.max(np.abs(run_steps(ref_steps, ref_l2p) - want)) > 0.3
+    steps, l2p = staging.atlas_stages(cd, 3, method="heuristic", strict_order=True)
+    assert l2p == ref_l2p
+    np.testing.assert_allclose(run_steps(steps, l2p), want, rtol=0, atol=1e-14)
+
+
+@pytest.mark.parametrize("name", ["qft_8", "rand_9", "clifft_9", "w_qft_6", "stg_8q", "stg_5q"])
+@pytest.mark.parametrize("k", [2, 3, 4, 5])
+def test_strict_order_staging_is_exact(name, k):
+    from oracle import dense_oracle as orc
+    cd = circuit_from_json(PLAN["circuits"][name])
+    if k >= cd["number_of_qubits"]:
+        pytest.skip("all local")
+    steps, l2p = staging.atlas_stages(cd, k, method="heuristic", strict_order=True)
+    psi = np.zeros(1 << cd["number_of_qubits"], dtype=np.complex128)
+    psi[0] = 1.0
+    for st in steps:
+        orc.apply_ops(psi, st["local_ops"])
+        orc.apply_ops(psi, st["nonlocal_ops"])
+    np.testing.assert_allclose(orc.permute_state(psi, l2p), orc.simulate(validate_circuit_dict(cd)),
+                               rtol=0, atol=1e-13)
