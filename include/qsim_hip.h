@@ -75,6 +75,13 @@ int qsim_apply_2q(qsim_chunk* c, int qa, int qb, const double U[32]);
  * nq[i] in {1,2}; qubits[2*i], qubits[2*i+1]; mats + 32*i holds U (8 or 32 doubles). */
 int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits,
                    const double* mats);
+/* qsim_apply_ops groups the pass into fused LDS-tile launches (one HBM round trip for many
+ * gates; op order is kept for every pair of ops that share a qubit).  The _unfused form
+ * issues one kernel per op, in list order; qsim_last_pass_count reports how many HBM round
+ * trips the last qsim_apply_ops on this chunk took.                                        */
+int qsim_apply_ops_unfused(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits,
+                           const double* mats);
+int qsim_last_pass_count(const qsim_chunk* c);
 
 /* ---- partner-chunk butterflies (cpu_nonlocal.*) ----------------------------------- */
 int qsim_apply_1q_pair(qsim_chunk* c0, qsim_chunk* c1, const double U[8]);

@@ -67,6 +67,7 @@ struct qsim_chunk {
   hipEvent_t ev0, ev1;   // timing
   bool have_events;
   double* scratch;       // reduction workspace (lazily allocated, owned)
+  int last_passes;       // HBM passes of the last qsim_apply_ops
 };
 
 static const int kMaxDevices = 16;
@@ -305,7 +306,21 @@ struct Tuning {
   int swz_cut = 64;   // XCD-contiguous block order when the highest removed bit is below this (r01 scan: always)
   int force_nt = -1;  // -1 auto, 0 never, 1 always
   int items = 0;      // 0 auto
+  int tile_bits = 11; // LDS tile = 2^tile_bits amplitudes (8..12); r01 scan: 11 beats 12 and 10
+  int max_gates_per_pass = 48;
+  int tile_wgs_per_cu = 8;   // upper bound; the occupancy query decides
+  int num_cus = 256;
+  int debug_skip_gates = 0;  // QSIM_DEBUG_SKIP_GATES=1: tile passes move data but apply nothing (WRONG results)
+  int tile_persistent = 0;   // r01: one-shot grid (5 WGs/CU) beats the persistent prefetching form (3 WGs/CU)
   Tuning() {
+    if (const char* e = getenv("QSIM_TILE_PERSIST")) tile_persistent = atoi(e);
+    if (const char* e = getenv("QSIM_DEBUG_SKIP_GATES")) debug_skip_gates = atoi(e);
+    if (const char* e = getenv("QSIM_TILE_WGS")) tile_wgs_per_cu = std::max(1, atoi(e));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) == hipSuccess && prop.multiProcessorCount > 0)
+      num_cus = prop.multiProcessorCount;
+    if (const char* e = getenv("QSIM_TILE_BITS")) tile_bits = std::min(12, std::max(8, atoi(e)));
+    if (const char* e = getenv("QSIM_PASS_GATES")) max_gates_per_pass = std::max(1, atoi(e));
     if (const char* e = getenv("QSIM_SWZ_CUT")) swz_cut = atoi(e);
     if (const char* e = getenv("QSIM_NT")) force_nt = atoi(e);
     if (const char* e = getenv("QSIM_ITEMS")) items = atoi(e);
@@ -588,6 +603,525 @@ static int gate_2q(const Group& g, int qa, int qb, const double* U, hipStream_t 
   }
   if (rc) return rc;
   return launch_plan(p, stream);
+}
+
+// ================================================================== fused tile passes
+// One HBM round trip applies MANY gates (the GPU form of the reference's level batching,
+// wenbo_engine/circuit/fusion.py:86-142, and of v3's fused independent-gate block,
+// parallel_gate_applicator.py:169-204): a workgroup loads a *tile* of 2^T amplitudes into LDS,
+// applies every gate of the pass whose target bits are tile bits, and stores the tile back.
+//   tile bits = the kTileLow lowest index bits (so every global access is a run of
+//   2^kTileLow amplitudes = 256 B, whole lines, NT) + up to T - kTileLow arbitrary higher bits.
+//   Control bits and diagonal bits may lie OUTSIDE the tile: they become a per-tile predicate.
+// Inside the tile gates are applied in *register groups*: a group owns kGroupBits tile bits;
+// each thread pulls the 2^kGroupBits amplitudes that differ in those bits from LDS, applies
+// every gate of the group in registers, and writes them back once -- LDS traffic is paid per
+// group, not per gate (measured: the per-gate LDS loop was LDS-write bound, 79 B/clk/CU).
+// LDS slots are XOR-swizzled (slot = t ^ ((t >> 4) & 15)) so both the global-side row accesses
+// and the register-group accesses on low tile bits are bank-conflict free.
+// Algorithmic bytes per pass: 32 B x 2^k (every amplitude read and written once), for g gates.
+constexpr int kTileLow = 4;
+constexpr int kGroupBits = 3;
+constexpr int kGroupAmps = 1 << kGroupBits;
+constexpr int kTileMaxGates = 56;      // gate entries incl. group headers
+constexpr int kTileMaxMat = 176;       // double2 entries (kernel-argument budget: 4 KiB in total)
+
+enum : uint8_t {
+  TG_DENSE1 = 0,   // 2x2 on register bit j0
+  TG_PHASE = 1,    // multiply selected amplitudes by mat[0]
+  TG_DENSE2 = 2,   // 4x4 on register bits (j0 = qa, j1 = qb)
+  TG_ANTI1 = 3,    // 2x2 with zero diagonal: a' = u01 b, b' = u10 a   (Y, CY)
+  TG_SWAP1 = 4,    // a <-> b                                        (X, CNOT)
+  TG_GROUP = 0xFE  // header: j0, j1, reg_mask hold the group's three tile bits (ascending)
+};
+
+struct alignas(16) TileGate {   // 16 bytes: one s_load_dwordx4
+  uint8_t kind;
+  uint8_t j0, j1;          // register bit indices (0 .. kGroupBits-1)
+  uint8_t reg_mask;        // register bits that must be 1 (controls / phase bits inside the group)
+  uint8_t blk0, blk1;      // tile bits outside the group that must be 1 (0xFF = unused)
+  uint8_t outer0, outer1;  // absolute index bits outside the tile that must be 1 (0xFF = unused)
+  uint16_t mat;            // first entry in TileArgs::mat
+  uint16_t count;          // group header: gates in the group
+  uint32_t pad;
+};
+
+struct TileArgs {
+  double2* amp;
+  int nh;                  // tile high bits
+  int ngates;
+  uint8_t h[16];           // ascending absolute positions of the tile's high bits
+  TileGate g[kTileMaxGates];
+  double2 mat[kTileMaxMat];
+};
+static_assert(sizeof(TileArgs) <= 4096, "kernel arguments must fit 4 KiB");
+
+__device__ __forceinline__ unsigned insert_zero(unsigned c, int p) {
+  return ((c >> p) << (p + 1)) | (c & ((1u << p) - 1));
+}
+__device__ __forceinline__ unsigned lds_slot(unsigned t) { return t ^ ((t >> 4) & 15u); }
+
+template <int J>
+__device__ __forceinline__ void reg_dense1(double2 (&x)[kGroupAmps], const double2* m, unsigned rm) {
+  const double2 u00 = m[0], u01 = m[1], u10 = m[2], u11 = m[3];
+#pragma unroll
+  for (int i = 0; i < kGroupAmps; ++i) {
+    if ((i >> J) & 1) continue;
+    if ((i & rm) != rm) continue;
+    const double2 a = x[i], b = x[i | (1 << J)];
+    x[i] = cfma(u01, b, cmul(u00, a));
+    x[i | (1 << J)] = cfma(u11, b, cmul(u10, a));
+  }
+}
+template <int J>
+__device__ __forceinline__ void reg_anti1(double2 (&x)[kGroupAmps], const double2* m, unsigned rm) {
+  const double2 u01 = m[1], u10 = m[2];
+#pragma unroll
+  for (int i = 0; i < kGroupAmps; ++i) {
+    if ((i >> J) & 1) continue;
+    if ((i & rm) != rm) continue;
+    const double2 a = x[i], b = x[i | (1 << J)];
+    x[i] = cmul(u01, b);
+    x[i | (1 << J)] = cmul(u10, a);
+  }
+}
+template <int J>
+__device__ __forceinline__ void reg_swap1(double2 (&x)[kGroupAmps], unsigned rm) {
+#pragma unroll
+  for (int i = 0; i < kGroupAmps; ++i) {
+    if ((i >> J) & 1) continue;
+    if ((i & rm) != rm) continue;
+    const double2 a = x[i];
+    x[i] = x[i | (1 << J)];
+    x[i | (1 << J)] = a;
+  }
+}
+template <int JA, int JB>
+__device__ __forceinline__ void reg_dense2(double2 (&x)[kGroupAmps], const double2* m) {
+#pragma unroll
+  for (int i = 0; i < kGroupAmps; ++i) {
+    if (((i >> JA) & 1) || ((i >> JB) & 1)) continue;
+    const double2 v0 = x[i], v1 = x[i | (1 << JB)], v2 = x[i | (1 << JA)], v3 = x[i | (1 << JA) | (1 << JB)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double2 acc = cmul(m[4 * r], v0);
+      acc = cfma(m[4 * r + 1], v1, acc);
+      acc = cfma(m[4 * r + 2], v2, acc);
+      acc = cfma(m[4 * r + 3], v3, acc);
+      x[i | ((r & 2) ? (1 << JA) : 0) | ((r & 1) ? (1 << JB) : 0)] = acc;
+    }
+  }
+}
+
+// waves per SIMD the LDS footprint admits (160 KiB / tile bytes, one wave per SIMD per workgroup):
+// asking for it caps the VGPR budget so registers never limit residency below LDS
+#ifndef QSIM_TILE_WAVE_CAP
+#define QSIM_TILE_WAVE_CAP 4
+#endif
+constexpr int tile_waves(int T) {
+  return (160 * 1024) / ((1 << T) * 16) > QSIM_TILE_WAVE_CAP ? QSIM_TILE_WAVE_CAP : (160 * 1024) / ((1 << T) * 16);
+}
+
+template <int T, bool PERSIST>
+__global__ __launch_bounds__(kBlock, tile_waves(T)) void k_tile(const TileArgs a, const unsigned ntiles) {
+  constexpr int N = 1 << T;
+  constexpr int LOW = kTileLow;
+  constexpr int NH = T - LOW;                         // tile high bits (host guarantees a.nh == NH)
+  constexpr int PER = N / kBlock;                     // tile elements per thread (T >= 8)
+  constexpr int NBLK = N >> kGroupBits;               // register blocks per tile
+  constexpr int NB = (NBLK + kBlock - 1) / kBlock;    // register blocks per thread
+  __shared__ double2 lds[N];
+  const int tid = threadIdx.x;
+  // global index of a tile's element 0: the tile number enumerates the non-tile bits
+  auto tile_base = [&](unsigned tile) -> u64 {
+    u64 base = (u64)tile << LOW;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int p = a.h[j];
+      base = ((base >> p) << (p + 1)) | (base & ((1ull << p) - 1));
+    }
+    return base;
+  };
+  // element t = tid + kBlock * j -> row = (tid >> LOW) | (j << (8 - LOW)): the thread part of the
+  // offset is computed once, the j part is wave-uniform (scalar registers)
+  u64 off_tid = tid & ((1 << LOW) - 1);
+#pragma unroll
+  for (int i = 0; i < 8 - LOW && i < NH; ++i) off_tid |= (u64)((tid >> (LOW + i)) & 1) << a.h[i];
+  auto off_j = [&](int j) -> u64 {
+    u64 o = 0;
+#pragma unroll
+    for (int i = 8 - LOW; i < NH; ++i) o |= (u64)((j >> (i - (8 - LOW))) & 1) << a.h[i];
+    return o;
+  };
+  // Persistent workgroup, software-pipelined: while the gates of tile i run out of LDS, the
+  // global loads of tile i + gridDim.x are already in flight into registers.
+  unsigned tile = blockIdx.x;
+  u64 base = tile_base(tile);
+  double2 v[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) v[j] = ld_amp<true>(a.amp + base + off_tid + off_j(j));
+  for (;;) {
+#pragma unroll
+  for (int j = 0; j < PER; ++j) lds[lds_slot(tid + kBlock * j)] = v[j];
+  __syncthreads();
+  const unsigned next = tile + gridDim.x;
+  const bool has_next = PERSIST && next < ntiles;
+  u64 next_base = 0;
+  if (PERSIST && has_next) {
+    next_base = tile_base(next);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) v[j] = ld_amp<true>(a.amp + next_base + off_tid + off_j(j));
+  }
+
+  int gi = 0;
+  while (gi < a.ngates) {
+    gi = __builtin_amdgcn_readfirstlane(gi);          // keep the descriptor reads scalar
+    const TileGate hd = a.g[gi++];                    // group header
+    const int s0 = hd.j0, s1 = hd.j1, s2 = hd.reg_mask;   // ascending tile bits
+    const int ge = gi + hd.count;
+    double2 x[NB][kGroupAmps];
+    unsigned tb[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const unsigned blk = tid + b * kBlock;
+      tb[b] = insert_zero(insert_zero(insert_zero(blk, s0), s1), s2);
+      if (NBLK % kBlock == 0 || blk < NBLK) {
+#pragma unroll
+        for (int i = 0; i < kGroupAmps; ++i) {
+          const unsigned t = tb[b] | ((i & 1) << s0) | (((i >> 1) & 1) << s1) | (((i >> 2) & 1) << s2);
+          x[b][i] = lds[lds_slot(t)];
+        }
+      }
+    }
+    for (int q0 = gi; q0 < ge; ++q0) {
+      const int q = __builtin_amdgcn_readfirstlane(q0);
+      const TileGate g = a.g[q];
+      if (g.outer0 != 0xFF && !((base >> g.outer0) & 1)) continue;
+      if (g.outer1 != 0xFF && !((base >> g.outer1) & 1)) continue;
+      const double2* m = a.mat + g.mat;
+      const unsigned rm = g.reg_mask;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (g.blk0 != 0xFF && !((tb[b] >> g.blk0) & 1)) continue;
+        if (g.blk1 != 0xFF && !((tb[b] >> g.blk1) & 1)) continue;
+        switch (g.kind) {
+          case TG_DENSE1:
+            if (g.j0 == 0) reg_dense1<0>(x[b], m, rm); else if (g.j0 == 1) reg_dense1<1>(x[b], m, rm); else reg_dense1<2>(x[b], m, rm);
+            break;
+          case TG_ANTI1:
+            if (g.j0 == 0) reg_anti1<0>(x[b], m, rm); else if (g.j0 == 1) reg_anti1<1>(x[b], m, rm); else reg_anti1<2>(x[b], m, rm);
+            break;
+          case TG_SWAP1:
+            if (g.j0 == 0) reg_swap1<0>(x[b], rm); else if (g.j0 == 1) reg_swap1<1>(x[b], rm); else reg_swap1<2>(x[b], rm);
+            break;
+          case TG_PHASE: {
+            const double2 d = m[0];
+#pragma unroll
+            for (int i = 0; i < kGroupAmps; ++i)
+              if ((i & rm) == rm) x[b][i] = cmul(d, x[b][i]);
+            break;
+          }
+          default: {
+            const int key = g.j0 * 3 + g.j1;
+            if (key == 1) reg_dense2<0, 1>(x[b], m); else if (key == 2) reg_dense2<0, 2>(x[b], m);
+            else if (key == 3) reg_dense2<1, 0>(x[b], m); else if (key == 5) reg_dense2<1, 2>(x[b], m);
+            else if (key == 6) reg_dense2<2, 0>(x[b], m); else reg_dense2<2, 1>(x[b], m);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (NBLK % kBlock == 0 || tid + b * kBlock < NBLK) {
+#pragma unroll
+        for (int i = 0; i < kGroupAmps; ++i) {
+          const unsigned t = tb[b] | ((i & 1) << s0) | (((i >> 1) & 1) << s1) | (((i >> 2) & 1) << s2);
+          lds[lds_slot(t)] = x[b][i];
+        }
+      }
+    }
+    __syncthreads();
+    gi = ge;
+  }
+  {
+    double2 w[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) w[j] = lds[lds_slot(tid + kBlock * j)];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) st_amp<true>(a.amp + base + off_tid + off_j(j), w[j]);
+  }
+  if (!PERSIST || !has_next) break;
+  tile = next;
+  base = next_base;
+  }  // persistent tile loop (each thread re-writes only the LDS slots it just read: no barrier)
+}
+
+// ---- host planner: op list -> passes -> register groups ----------------------------------------
+struct FusedOp {
+  int kind;            // TG_DENSE1 / TG_ANTI1 / TG_SWAP1 (target, optional control), TG_PHASE, TG_DENSE2
+  int target[2];       // 1q kinds: target[0]; TG_DENSE2: (qa, qb)
+  int ntargets;
+  int control;         // 1q kinds: control qubit or -1
+  int bits[2];         // TG_PHASE: qubits that must be 1
+  int nbits;
+  int qubits[2];       // every qubit the op touches (for ordering)
+  int nq;
+  double2 m[16];
+  int nm;              // matrix entries (4, 1 or 16)
+};
+
+static void set_1q_kind(FusedOp* o) {   // o->m holds the 2x2
+  const bool zero_diag = o->m[0].x == 0 && o->m[0].y == 0 && o->m[3].x == 0 && o->m[3].y == 0;
+  const bool ones = o->m[1].x == 1 && o->m[1].y == 0 && o->m[2].x == 1 && o->m[2].y == 0;
+  o->kind = zero_diag ? (ones ? TG_SWAP1 : TG_ANTI1) : TG_DENSE1;
+}
+
+// Same classification as gate_1q / gate_2q; returns false for an identity.
+static bool classify_op(int nq, const int32_t* q, const double* U, FusedOp* o) {
+  o->nq = nq;
+  o->qubits[0] = q[0];
+  o->qubits[1] = nq == 2 ? q[1] : -1;
+  o->control = -1;
+  o->nbits = 0;
+  o->ntargets = 0;
+  auto C = [&](int i) { return make_double2(U[2 * i], U[2 * i + 1]); };
+  if (nq == 1) {
+    const bool diag = is_zero(U[2], U[3]) && is_zero(U[4], U[5]);
+    if (diag && is_one(U[0], U[1])) {
+      if (is_one(U[6], U[7])) return false;
+      o->kind = TG_PHASE; o->bits[0] = q[0]; o->nbits = 1; o->m[0] = C(3); o->nm = 1;
+      return true;
+    }
+    o->target[0] = q[0]; o->ntargets = 1;
+    for (int i = 0; i < 4; ++i) o->m[i] = C(i);
+    o->nm = 4;
+    set_1q_kind(o);
+    return true;
+  }
+  auto z = [&](int r, int c) { return is_zero(U[2 * (4 * r + c)], U[2 * (4 * r + c) + 1]); };
+  auto one = [&](int r, int c) { return is_one(U[2 * (4 * r + c)], U[2 * (4 * r + c) + 1]); };
+  bool offdiag_zero = true;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c)
+      if (r != c && !z(r, c)) offdiag_zero = false;
+  const bool ctrl_a = one(0, 0) && one(1, 1) && z(0, 1) && z(1, 0) && z(0, 2) && z(0, 3) && z(1, 2) &&
+                      z(1, 3) && z(2, 0) && z(2, 1) && z(3, 0) && z(3, 1);
+  const bool ctrl_b = one(0, 0) && one(2, 2) && z(0, 2) && z(2, 0) && z(0, 1) && z(0, 3) && z(2, 1) &&
+                      z(2, 3) && z(1, 0) && z(1, 2) && z(3, 0) && z(3, 2);
+  if (offdiag_zero && one(0, 0) && one(1, 1) && one(2, 2)) {
+    if (one(3, 3)) return false;
+    o->kind = TG_PHASE; o->bits[0] = q[0]; o->bits[1] = q[1]; o->nbits = 2; o->m[0] = C(15); o->nm = 1;
+    return true;
+  }
+  if (ctrl_a || ctrl_b) {
+    o->control = ctrl_a ? q[0] : q[1];
+    o->target[0] = ctrl_a ? q[1] : q[0];
+    o->ntargets = 1;
+    if (ctrl_a) { o->m[0] = C(10); o->m[1] = C(11); o->m[2] = C(14); o->m[3] = C(15); }
+    else        { o->m[0] = C(5);  o->m[1] = C(7);  o->m[2] = C(13); o->m[3] = C(15); }
+    o->nm = 4;
+    set_1q_kind(o);
+    if (o->kind == TG_DENSE1 && o->m[1].x == 0 && o->m[1].y == 0 && o->m[2].x == 0 && o->m[2].y == 0 &&
+        o->m[0].x == 1 && o->m[0].y == 0) {   // controlled phase written as CU: diag(1, d)
+      o->kind = TG_PHASE; o->bits[0] = q[0]; o->bits[1] = q[1]; o->nbits = 2; o->m[0] = o->m[3]; o->nm = 1;
+      o->ntargets = 0; o->control = -1;
+    }
+    return true;
+  }
+  o->kind = TG_DENSE2; o->target[0] = q[0]; o->target[1] = q[1]; o->ntargets = 2;
+  for (int i = 0; i < 16; ++i) o->m[i] = C(i);
+  o->nm = 16;
+  return true;
+}
+
+template <int T>
+static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t stream) {
+  const u64 ntiles = 1ull << (c->k - T);
+  ProfileScope prof(6, 32.0 * (double)amps(c), stream);
+  if (tuning().tile_persistent) {
+    // persistent grid: as many workgroups as stay resident, each walks tiles b, b + grid, ...
+    static int resident = 0;
+    if (!resident) {
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile<T, true>, kBlock, 0) != hipSuccess || n < 1) n = 1;
+      resident = n;
+    }
+    const int per_cu = std::max(1, std::min(tuning().tile_wgs_per_cu, resident));
+    const u64 blocks = std::min<u64>(ntiles, (u64)tuning().num_cus * per_cu);
+    hipLaunchKernelGGL((k_tile<T, true>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, (unsigned)ntiles);
+  } else {
+    hipLaunchKernelGGL((k_tile<T, false>), dim3((unsigned)ntiles), dim3(kBlock), 0, stream, a, (unsigned)ntiles);
+  }
+  prof.done(stream);
+  HIP_TRY(hipGetLastError());
+  return QSIM_OK;
+}
+
+static int launch_tile_any(const TileArgs& a, int T, const qsim_chunk* c, hipStream_t stream) {
+  switch (T) {
+    case 8: return launch_tile<8>(a, c, stream);
+    case 9: return launch_tile<9>(a, c, stream);
+    case 10: return launch_tile<10>(a, c, stream);
+    case 11: return launch_tile<11>(a, c, stream);
+    case 12: return launch_tile<12>(a, c, stream);
+  }
+  return fail(QSIM_ERR_INVALID, "internal: tile size %d", T);
+}
+
+constexpr int kTileMinChunk = 8;   // smaller chunks run gate by gate
+
+static inline u64 op_qmask(const FusedOp& o) {
+  u64 m = 1ull << o.qubits[0];
+  if (o.nq == 2) m |= 1ull << o.qubits[1];
+  return m;
+}
+
+// Split one pass's ops (list order) into register groups of <= kGroupBits target tile bits and
+// emit the gate stream.  Returns false when the stream does not fit the kernel arguments; then
+// `taken` ops (a prefix-closed subset) were emitted and the caller re-queues the rest.
+static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_t>& members,
+                        const std::vector<int>& high, int T, TileArgs* a, std::vector<char>* emitted) {
+  const int low = kTileLow;
+  auto tile_pos = [&](int b) -> int {
+    if (b < low) return b;
+    for (size_t j = 0; j < high.size(); ++j) if (high[j] == b) return low + (int)j;
+    return -1;
+  };
+  std::vector<char> done(members.size(), 0);
+  size_t left = members.size();
+  int mat = 0;
+  a->ngates = 0;
+  while (left) {
+    std::vector<int> S;               // tile bits of this group
+    std::vector<size_t> grp;          // indices into members
+    u64 blocked = 0;
+    int mat_need = 0;
+    for (size_t mi = 0; mi < members.size(); ++mi) {
+      if (done[mi]) continue;
+      const FusedOp& o = ops[members[mi]];
+      const u64 qm = op_qmask(o);
+      bool ok = !(blocked & qm);
+      int need[2], nneed = 0;
+      if (ok) {
+        for (int t = 0; t < o.ntargets; ++t) {
+          const int p = tile_pos(o.target[t]);
+          if (std::find(S.begin(), S.end(), p) == S.end()) need[nneed++] = p;
+        }
+        if ((int)S.size() + nneed > kGroupBits) ok = false;
+        if (a->ngates + 1 + (int)grp.size() + 1 > kTileMaxGates) ok = false;
+        if (mat + mat_need + o.nm > kTileMaxMat) ok = false;
+      }
+      if (!ok) { blocked |= qm; continue; }
+      for (int t = 0; t < nneed; ++t) S.push_back(need[t]);
+      grp.push_back(mi);
+      mat_need += o.nm;
+    }
+    if (grp.empty()) break;           // argument budget exhausted: the rest waits for the next launch
+    // pad the group with the highest unused tile bits (high bits keep LDS accesses contiguous)
+    for (int b = T - 1; (int)S.size() < kGroupBits && b >= 0; --b)
+      if (std::find(S.begin(), S.end(), b) == S.end()) S.push_back(b);
+    std::sort(S.begin(), S.end());
+    auto reg_pos = [&](int tile_bit) -> int {
+      for (int j = 0; j < kGroupBits; ++j) if (S[j] == tile_bit) return j;
+      return -1;
+    };
+    TileGate hd;
+    std::memset(&hd, 0xFF, sizeof hd);
+    hd.kind = TG_GROUP; hd.j0 = (uint8_t)S[0]; hd.j1 = (uint8_t)S[1]; hd.reg_mask = (uint8_t)S[2]; hd.mat = 0;
+    hd.count = (uint16_t)grp.size();
+    a->g[a->ngates++] = hd;
+    for (size_t mi : grp) {
+      const FusedOp& o = ops[members[mi]];
+      TileGate g;
+      std::memset(&g, 0xFF, sizeof g);
+      g.kind = (uint8_t)o.kind;
+      g.j0 = g.j1 = 0;
+      g.reg_mask = 0;
+      g.mat = (uint16_t)mat;
+      int nblk = 0, nouter = 0;
+      auto require_one = [&](int qubit) {      // a control / phase bit
+        const int p = tile_pos(qubit);
+        if (p < 0) { (nouter++ == 0 ? g.outer0 : g.outer1) = (uint8_t)qubit; return; }
+        const int r = reg_pos(p);
+        if (r >= 0) g.reg_mask |= (uint8_t)(1u << r);
+        else (nblk++ == 0 ? g.blk0 : g.blk1) = (uint8_t)p;
+      };
+      if (o.kind == TG_PHASE) {
+        for (int t = 0; t < o.nbits; ++t) require_one(o.bits[t]);
+      } else if (o.kind == TG_DENSE2) {
+        g.j0 = (uint8_t)reg_pos(tile_pos(o.target[0]));
+        g.j1 = (uint8_t)reg_pos(tile_pos(o.target[1]));
+      } else {
+        g.j0 = (uint8_t)reg_pos(tile_pos(o.target[0]));
+        if (o.control >= 0) require_one(o.control);
+      }
+      for (int e = 0; e < o.nm; ++e) a->mat[mat + e] = o.m[e];
+      mat += o.nm;
+      a->g[a->ngates++] = g;
+      done[mi] = 1;
+      (*emitted)[mi] = 1;
+      --left;
+    }
+  }
+}
+
+// Greedy pass builder.  Ops are taken in list order; an op that does not fit the current tile
+// blocks its qubits, and later ops on blocked qubits wait for the next pass, so any two ops
+// sharing a qubit keep their order (ops on disjoint qubits commute).
+static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_passes) {
+  const int k = c->k;
+  const Tuning& tune = tuning();
+  const int T = k < tune.tile_bits ? k : tune.tile_bits;
+  const int low = kTileLow;
+  const int cap = T - low;                      // tile high-bit capacity
+  std::vector<char> done(ops.size(), 0);
+  size_t remaining = ops.size();
+  size_t first = 0;
+  *n_passes = 0;
+  while (remaining) {
+    std::vector<int> high;                      // chosen high bits
+    std::vector<size_t> members;
+    u64 blocked = 0;
+    while (first < ops.size() && done[first]) ++first;
+    for (size_t i = first; i < ops.size() && (int)members.size() < tune.max_gates_per_pass; ++i) {
+      if (done[i]) continue;
+      const FusedOp& o = ops[i];
+      const u64 qmask = op_qmask(o);
+      bool ok = !(blocked & qmask);
+      int need[2], nneed = 0;
+      if (ok) {
+        for (int t = 0; t < o.ntargets; ++t) {
+          const int b = o.target[t];
+          if (b >= low && std::find(high.begin(), high.end(), b) == high.end()) need[nneed++] = b;
+        }
+        if ((int)high.size() + nneed > cap) ok = false;
+      }
+      if (!ok) { blocked |= qmask; continue; }
+      for (int t = 0; t < nneed; ++t) high.push_back(need[t]);
+      members.push_back(i);
+    }
+    if (members.empty()) return fail(QSIM_ERR_INVALID, "internal: fused planner made no progress");
+    // fill the tile with the lowest unused bits so it always has T bits
+    for (int b = low; (int)high.size() < cap && b < k; ++b)
+      if (std::find(high.begin(), high.end(), b) == high.end()) high.push_back(b);
+    std::sort(high.begin(), high.end());
+    TileArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.amp = c->amp;
+    a.nh = (int)high.size();
+    for (int j = 0; j < a.nh; ++j) a.h[j] = (uint8_t)high[j];
+    std::vector<char> emitted(members.size(), 0);
+    emit_groups(ops, members, high, T, &a, &emitted);
+    size_t n_emitted = 0;
+    for (size_t mi = 0; mi < members.size(); ++mi)
+      if (emitted[mi]) { done[members[mi]] = 1; --remaining; ++n_emitted; }
+    if (!n_emitted) return fail(QSIM_ERR_INVALID, "internal: fused planner emitted nothing");
+    if (tune.debug_skip_gates) a.ngates = 0;       // profiling aid: load -> LDS -> store only
+    int rc = launch_tile_any(a, T, c, c->stream);
+    if (rc) return rc;
+    ++*n_passes;
+  }
+  return QSIM_OK;
 }
 
 // ------------------------------------------------------------------ argument checks
@@ -949,7 +1483,7 @@ int qsim_apply_2q(qsim_chunk* c, int qa, int qb, const double U[32]) {
   return gate_2q(g, qa, qb, U, c->stream);
 }
 
-int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats) {
+static int validate_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats) {
   int rc = check_chunk(c, "qsim_apply_ops");
   if (rc) return rc;
   if (n_ops < 0 || (n_ops && (!nq || !qubits || !mats))) return fail(QSIM_ERR_INVALID, "bad op list");
@@ -960,6 +1494,12 @@ int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* q
     if (nq[i] == 2 && qubits[2 * i] == qubits[2 * i + 1])
       return fail(QSIM_ERR_INVALID, "op %d: repeated qubit", i);
   }
+  return QSIM_OK;
+}
+
+int qsim_apply_ops_unfused(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats) {
+  int rc = validate_ops(c, n_ops, nq, qubits, mats);
+  if (rc) return rc;
   for (int i = 0; i < n_ops; ++i) {
     rc = nq[i] == 1 ? qsim_apply_1q(c, qubits[2 * i], mats + 32 * (size_t)i)
                     : qsim_apply_2q(c, qubits[2 * i], qubits[2 * i + 1], mats + 32 * (size_t)i);
@@ -967,6 +1507,28 @@ int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* q
   }
   return QSIM_OK;
 }
+
+int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats) {
+  int rc = validate_ops(c, n_ops, nq, qubits, mats);
+  if (rc) return rc;
+  if (n_ops < 2 || c->k < kTileMinChunk) {
+    c->last_passes = n_ops;
+    return qsim_apply_ops_unfused(c, n_ops, nq, qubits, mats);
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  std::vector<FusedOp> ops;
+  ops.reserve(n_ops);
+  for (int i = 0; i < n_ops; ++i) {
+    FusedOp o;
+    if (classify_op(nq[i], qubits + 2 * i, mats + 32 * (size_t)i, &o)) ops.push_back(o);
+  }
+  int passes = 0;
+  rc = run_fused(c, ops, &passes);
+  c->last_passes = passes;
+  return rc;
+}
+
+int qsim_last_pass_count(const qsim_chunk* c) { return c ? c->last_passes : -1; }
 
 int qsim_apply_1q_pair(qsim_chunk* c0, qsim_chunk* c1, const double U[8]) {
   qsim_chunk* cs[2] = {c0, c1};

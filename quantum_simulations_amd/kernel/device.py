@@ -128,14 +128,17 @@ class DeviceChunk:
         m, p = _mat_ptr(U, 4)
         _lib.check(_lib.load().qsim_apply_2q(self._h, int(qa), int(qb), p))
 
-    def apply_ops(self, ops) -> None:
-        """One pass: every (qubits, U) of `ops`, in order, in one C call."""
+    def apply_ops(self, ops, fused: bool = True) -> int:
+        """One pass: every (qubits, U) of `ops` in one C call.  `fused` groups them into LDS-tile
+        launches (order kept for ops sharing a qubit); returns the number of HBM round trips."""
         if not ops:
-            return
+            return 0
         nq, qs, mats = pack_ops(ops)
-        _lib.check(_lib.load().qsim_apply_ops(
-            self._h, len(ops), nq.ctypes.data_as(C.c_void_p), qs.ctypes.data_as(C.c_void_p),
-            mats.ctypes.data_as(C.c_void_p)))
+        lib = _lib.load()
+        fn = lib.qsim_apply_ops if fused else lib.qsim_apply_ops_unfused
+        _lib.check(fn(self._h, len(ops), nq.ctypes.data_as(C.c_void_p), qs.ctypes.data_as(C.c_void_p),
+                      mats.ctypes.data_as(C.c_void_p)))
+        return lib.qsim_last_pass_count(self._h) if fused else len(ops)
 
     # ---- sync / reductions / timing -------------------------------------------------
     def sync(self) -> None:

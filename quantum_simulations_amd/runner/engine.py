@@ -60,11 +60,13 @@ class SingleGpuEngine:
         return [p["local_ops"] for p in batch_levels(levelize(cd), self.n)]
 
     def execute(self, plan: list) -> None:
+        self.last_passes = 0
         for ops in plan:
-            self.state.apply_ops(ops)
+            self.last_passes += self.state.apply_ops(ops, fused=self.mode != "per-gate")
 
     def passes_per_step(self, plan: list) -> int:
-        return sum(len(ops) for ops in plan)  # until tile fusion: one HBM pass per op
+        """HBM round trips of the last executed step (fused tile launches or single gates)."""
+        return getattr(self, "last_passes", sum(len(ops) for ops in plan))
 
     # ---- synchronisation / measurement --------------------------------------------------
     def barrier(self) -> None:

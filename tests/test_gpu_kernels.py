@@ -249,3 +249,80 @@ def test_full_size_28q_unitarity_roundtrip(hip):
     np.testing.assert_allclose(dev.download(0, 1 << 16), before, rtol=0, atol=1e-12)
     np.testing.assert_allclose(dev.download((1 << n) - 4096, 4096), tail, rtol=0, atol=1e-12)
     dev.close()
+
+
+# ---------------------------------------------------------------- fused LDS-tile passes
+def _random_ops(n, n_ops, seed):
+    rng = np.random.default_rng(seed)
+    names1 = ["H", "X", "Y", "Z", "S", "T", "RY", "R", "G", "U", "D"]
+    names2 = ["CNOT", "CZ", "CY", "SWAP", "CR", "CU", "U4", "CTRL_B", "DIAG4"]
+    ops = []
+    for i in range(n_ops):
+        if n == 1 or rng.random() < 0.55:
+            nm = names1[int(rng.integers(len(names1)))]
+            q = int(rng.integers(n))
+            if nm == "U":
+                U = _rand_unitary(2, seed * 1000 + i)
+            elif nm == "D":
+                U = np.diag(np.exp(1j * rng.uniform(0, 6, 2)))
+            else:
+                U = orc.gate_matrix(nm, {"theta": float(rng.uniform(0, 6)), "k": int(rng.integers(1, 6)),
+                                         "p": int(rng.integers(2, 6))})
+            ops.append(([q], U))
+        else:
+            nm = names2[int(rng.integers(len(names2)))]
+            qa, qb = (int(x) for x in rng.choice(n, size=2, replace=False))
+            if nm == "U4":
+                U = _rand_unitary(4, seed * 1000 + i)
+            elif nm == "CTRL_B":
+                U = orc.gate_matrix("CY")[np.ix_([0, 2, 1, 3], [0, 2, 1, 3])]
+            elif nm == "DIAG4":
+                U = np.diag(np.exp(1j * rng.uniform(0, 6, 4)))
+            else:
+                U = orc.gate_matrix(nm, {"k": int(rng.integers(1, 6)), "U": orc.gate_matrix("G", {"p": 3}),
+                                         "exponent": int(rng.integers(1, 3))})
+            ops.append(([qa, qb], U))
+    return ops
+
+
+@pytest.mark.parametrize("n", [8, 9, 11, 12, 13, 16, 18])
+def test_fused_tile_passes_vs_oracle(hip, n):
+    for seed in range(3):
+        ops = _random_ops(n, 90, 50 * n + seed)
+        psi0 = _rand_state(n, 700 + n + seed)
+        want = psi0.copy()
+        orc.apply_ops(want, ops)
+        dev = hip.DeviceChunk.from_numpy(psi0)
+        passes = dev.apply_ops(ops, fused=True)
+        got = dev.download()
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-11, err_msg=f"n={n} seed={seed}")
+        assert 1 <= passes <= len(ops)
+        dev.upload(psi0)
+        assert dev.apply_ops(ops, fused=False) == len(ops)
+        np.testing.assert_allclose(dev.download(), want, rtol=0, atol=1e-11)
+        dev.close()
+
+
+def test_fused_pass_counts_and_layer_structure(hip):
+    """A 1q layer on 20 qubits needs ceil((20-4)/(T-4)) tile passes (T = 11: 3), not 20; CNOT
+    controls and CZ/T bits outside the tile ride along as predicates."""
+    n = 20
+    H, T, CX, CZ = (orc.gate_matrix(g) for g in ("H", "T", "CNOT", "CZ"))
+    layer = [([q], H) for q in range(n)]
+    dev = hip.DeviceChunk.zero_state(n)
+    assert dev.apply_ops(layer) in (2, 3)
+    np.testing.assert_allclose(np.abs(dev.download(0, 4096)), 2.0 ** (-n / 2), atol=1e-14)
+    diag = [([q], T) for q in range(n)] + [([q, (q + 7) % n], CZ) for q in range(n)]
+    assert dev.apply_ops(diag) == 1          # all-diagonal: one pass whatever the qubits
+    ctrl = [([19 - q, q], CX) for q in range(7)]   # controls 19..13 outside / targets 0..6
+    assert dev.apply_ops(ctrl) == 1
+    psi = np.full(1 << 12, 2.0 ** -6, dtype=np.complex128)
+    ops12 = [([q], T) for q in range(12)] + [([q, (q + 5) % 12], CZ) for q in range(12)] + \
+            [([11 - q, q], CX) for q in range(4)]
+    want = psi.copy()
+    orc.apply_ops(want, ops12)
+    d12 = hip.DeviceChunk.from_numpy(psi)
+    d12.apply_ops(ops12)
+    np.testing.assert_allclose(d12.download(), want, rtol=0, atol=1e-13)
+    d12.close()
+    dev.close()
