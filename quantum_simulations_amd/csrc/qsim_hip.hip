@@ -620,7 +620,10 @@ static int gate_2q(const Group& g, int qa, int qb, const double* U, hipStream_t 
 // LDS slots are XOR-swizzled (slot = t ^ ((t >> 4) & 15)) so both the global-side row accesses
 // and the register-group accesses on low tile bits are bank-conflict free.
 // Algorithmic bytes per pass: 32 B x 2^k (every amplitude read and written once), for g gates.
-constexpr int kTileLow = 4;
+#ifndef QSIM_TILE_LOW
+#define QSIM_TILE_LOW 3
+#endif
+constexpr int kTileLow = QSIM_TILE_LOW;
 constexpr int kGroupBits = 3;
 constexpr int kGroupAmps = 1 << kGroupBits;
 constexpr int kTileMaxGates = 56;      // gate entries incl. group headers
@@ -713,23 +716,27 @@ __device__ __forceinline__ void reg_dense2(double2 (&x)[kGroupAmps], const doubl
   }
 }
 
-// waves per SIMD the LDS footprint admits (160 KiB / tile bytes, one wave per SIMD per workgroup):
-// asking for it caps the VGPR budget so registers never limit residency below LDS
-#ifndef QSIM_TILE_WAVE_CAP
-#define QSIM_TILE_WAVE_CAP 4
+// The gate loop is bound by the CU's single scalar unit (descriptor decode + uniform branches
+// are paid per wave per gate), so a tile is worked by FEW waves with MORE register blocks each:
+// kTileThreads = 128 (2 waves, 2 blocks of 8 amplitudes per thread at T = 11) measured faster
+// than 256 threads (4 waves, 1 block).
+#ifndef QSIM_TILE_THREADS
+#define QSIM_TILE_THREADS 256
 #endif
-constexpr int tile_waves(int T) {
-  return (160 * 1024) / ((1 << T) * 16) > QSIM_TILE_WAVE_CAP ? QSIM_TILE_WAVE_CAP : (160 * 1024) / ((1 << T) * 16);
-}
+constexpr int kTileThreads = QSIM_TILE_THREADS;
+constexpr int kTileThreadBits = kTileThreads == 64 ? 6 : (kTileThreads == 128 ? 7 : (kTileThreads == 256 ? 8 : (kTileThreads == 512 ? 9 : 10)));
 
 template <int T, bool PERSIST>
-__global__ __launch_bounds__(kBlock, tile_waves(T)) void k_tile(const TileArgs a, const unsigned ntiles) {
+__global__ __launch_bounds__(kTileThreads) void k_tile(const TileArgs a, const unsigned ntiles) {
   constexpr int N = 1 << T;
   constexpr int LOW = kTileLow;
   constexpr int NH = T - LOW;                         // tile high bits (host guarantees a.nh == NH)
-  constexpr int PER = N / kBlock;                     // tile elements per thread (T >= 8)
+  constexpr int BLOCK = kTileThreads;
+  constexpr int TB = kTileThreadBits;                 // thread id bits: LOW element bits + row bits
+  constexpr int PER = N / BLOCK > 0 ? N / BLOCK : 1;  // tile elements per thread
+  const bool elem_ok = N >= BLOCK || (int)threadIdx.x < N;   // tiny tiles: surplus threads idle
   constexpr int NBLK = N >> kGroupBits;               // register blocks per tile
-  constexpr int NB = (NBLK + kBlock - 1) / kBlock;    // register blocks per thread
+  constexpr int NB = (NBLK + BLOCK - 1) / BLOCK;      // register blocks per thread
   __shared__ double2 lds[N];
   const int tid = threadIdx.x;
   // global index of a tile's element 0: the tile number enumerates the non-tile bits
@@ -742,27 +749,25 @@ __global__ __launch_bounds__(kBlock, tile_waves(T)) void k_tile(const TileArgs a
     }
     return base;
   };
-  // element t = tid + kBlock * j -> row = (tid >> LOW) | (j << (8 - LOW)): the thread part of the
+  // element t = tid + BLOCK * j -> row = (tid >> LOW) | (j << (TB - LOW)): the thread part of the
   // offset is computed once, the j part is wave-uniform (scalar registers)
   u64 off_tid = tid & ((1 << LOW) - 1);
 #pragma unroll
-  for (int i = 0; i < 8 - LOW && i < NH; ++i) off_tid |= (u64)((tid >> (LOW + i)) & 1) << a.h[i];
+  for (int i = 0; i < TB - LOW && i < NH; ++i) off_tid |= (u64)((tid >> (LOW + i)) & 1) << a.h[i];   // tid < N
   auto off_j = [&](int j) -> u64 {
     u64 o = 0;
 #pragma unroll
-    for (int i = 8 - LOW; i < NH; ++i) o |= (u64)((j >> (i - (8 - LOW))) & 1) << a.h[i];
+    for (int i = TB - LOW; i < NH; ++i) o |= (u64)((j >> (i - (TB - LOW))) & 1) << a.h[i];
     return o;
   };
-  // Persistent workgroup, software-pipelined: while the gates of tile i run out of LDS, the
-  // global loads of tile i + gridDim.x are already in flight into registers.
   unsigned tile = blockIdx.x;
   u64 base = tile_base(tile);
   double2 v[PER];
 #pragma unroll
-  for (int j = 0; j < PER; ++j) v[j] = ld_amp<true>(a.amp + base + off_tid + off_j(j));
+  for (int j = 0; j < PER; ++j) if (elem_ok) v[j] = ld_amp<true>(a.amp + base + off_tid + off_j(j));
   for (;;) {
 #pragma unroll
-  for (int j = 0; j < PER; ++j) lds[lds_slot(tid + kBlock * j)] = v[j];
+  for (int j = 0; j < PER; ++j) if (elem_ok) lds[lds_slot(tid + BLOCK * j)] = v[j];
   __syncthreads();
   const unsigned next = tile + gridDim.x;
   const bool has_next = PERSIST && next < ntiles;
@@ -770,7 +775,7 @@ __global__ __launch_bounds__(kBlock, tile_waves(T)) void k_tile(const TileArgs a
   if (PERSIST && has_next) {
     next_base = tile_base(next);
 #pragma unroll
-    for (int j = 0; j < PER; ++j) v[j] = ld_amp<true>(a.amp + next_base + off_tid + off_j(j));
+    for (int j = 0; j < PER; ++j) if (elem_ok) v[j] = ld_amp<true>(a.amp + next_base + off_tid + off_j(j));
   }
 
   int gi = 0;
@@ -783,9 +788,9 @@ __global__ __launch_bounds__(kBlock, tile_waves(T)) void k_tile(const TileArgs a
     unsigned tb[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const unsigned blk = tid + b * kBlock;
+      const unsigned blk = tid + b * BLOCK;
       tb[b] = insert_zero(insert_zero(insert_zero(blk, s0), s1), s2);
-      if (NBLK % kBlock == 0 || blk < NBLK) {
+      if (NBLK % BLOCK == 0 || blk < NBLK) {
 #pragma unroll
         for (int i = 0; i < kGroupAmps; ++i) {
           const unsigned t = tb[b] | ((i & 1) << s0) | (((i >> 1) & 1) << s1) | (((i >> 2) & 1) << s2);
@@ -832,7 +837,7 @@ __global__ __launch_bounds__(kBlock, tile_waves(T)) void k_tile(const TileArgs a
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      if (NBLK % kBlock == 0 || tid + b * kBlock < NBLK) {
+      if (NBLK % BLOCK == 0 || tid + b * BLOCK < NBLK) {
 #pragma unroll
         for (int i = 0; i < kGroupAmps; ++i) {
           const unsigned t = tb[b] | ((i & 1) << s0) | (((i >> 1) & 1) << s1) | (((i >> 2) & 1) << s2);
@@ -846,9 +851,9 @@ __global__ __launch_bounds__(kBlock, tile_waves(T)) void k_tile(const TileArgs a
   {
     double2 w[PER];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) w[j] = lds[lds_slot(tid + kBlock * j)];
+    for (int j = 0; j < PER; ++j) if (elem_ok) w[j] = lds[lds_slot(tid + BLOCK * j)];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) st_amp<true>(a.amp + base + off_tid + off_j(j), w[j]);
+    for (int j = 0; j < PER; ++j) if (elem_ok) st_amp<true>(a.amp + base + off_tid + off_j(j), w[j]);
   }
   if (!PERSIST || !has_next) break;
   tile = next;
@@ -943,14 +948,14 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
     static int resident = 0;
     if (!resident) {
       int n = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile<T, true>, kBlock, 0) != hipSuccess || n < 1) n = 1;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile<T, true>, kTileThreads, 0) != hipSuccess || n < 1) n = 1;
       resident = n;
     }
     const int per_cu = std::max(1, std::min(tuning().tile_wgs_per_cu, resident));
     const u64 blocks = std::min<u64>(ntiles, (u64)tuning().num_cus * per_cu);
-    hipLaunchKernelGGL((k_tile<T, true>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, (unsigned)ntiles);
+    hipLaunchKernelGGL((k_tile<T, true>), dim3((unsigned)blocks), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
   } else {
-    hipLaunchKernelGGL((k_tile<T, false>), dim3((unsigned)ntiles), dim3(kBlock), 0, stream, a, (unsigned)ntiles);
+    hipLaunchKernelGGL((k_tile<T, false>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
   }
   prof.done(stream);
   HIP_TRY(hipGetLastError());

@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B several builds of libqsim_hip.so in ONE process sequence on ONE device (guide rule 24):
+#   tools/ab_libs.sh <rounds> libA.so libB.so ...   (libs inside quantum_simulations_amd/)
+rounds=$1; shift
+cd "$(dirname "$0")/.."
+cp quantum_simulations_amd/libqsim_hip.so /tmp/_orig_lib.so
+for r in $(seq 1 $rounds); do
+  for lib in "$@"; do
+    cp quantum_simulations_amd/$lib quantum_simulations_amd/libqsim_hip.so
+    printf "%s round %s: " "$lib" "$r"
+    timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['hbm_passes_per_step'], d['roofline']['avg_launch_ms'])"
+  done
+done
+cp /tmp/_orig_lib.so quantum_simulations_amd/libqsim_hip.so
