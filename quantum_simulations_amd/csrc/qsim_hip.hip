@@ -626,8 +626,8 @@ static int gate_2q(const Group& g, int qa, int qb, const double* U, hipStream_t 
 constexpr int kTileLow = QSIM_TILE_LOW;
 constexpr int kGroupBits = 3;
 constexpr int kGroupAmps = 1 << kGroupBits;
-constexpr int kTileMaxGates = 56;      // gate entries incl. group headers
-constexpr int kTileMaxMat = 176;       // double2 entries (kernel-argument budget: 4 KiB in total)
+constexpr int kTileMaxGates = 48;      // gate entries incl. group headers and padding
+constexpr int kTileMaxMat = 4 * kTileMaxGates;   // gate entry q owns mat[4q .. 4q+3] (fixed stride)
 
 enum : uint8_t {
   TG_DENSE1 = 0,   // 2x2 on register bit j0
@@ -635,18 +635,18 @@ enum : uint8_t {
   TG_DENSE2 = 2,   // 4x4 on register bits (j0 = qa, j1 = qb)
   TG_ANTI1 = 3,    // 2x2 with zero diagonal: a' = u01 b, b' = u10 a   (Y, CY)
   TG_SWAP1 = 4,    // a <-> b                                        (X, CNOT)
+  TG_NOP = 5,      // padding: the three entries after a 4x4 gate hold the rest of its matrix
   TG_GROUP = 0xFE  // header: j0, j1, reg_mask hold the group's three tile bits (ascending)
 };
 
-struct alignas(16) TileGate {   // 16 bytes: one s_load_dwordx4
+struct alignas(16) TileGate {   // 16 bytes: one s_load_dwordx4; predicates are ready-made masks
   uint8_t kind;
-  uint8_t j0, j1;          // register bit indices (0 .. kGroupBits-1)
-  uint8_t reg_mask;        // register bits that must be 1 (controls / phase bits inside the group)
-  uint8_t blk0, blk1;      // tile bits outside the group that must be 1 (0xFF = unused)
-  uint8_t outer0, outer1;  // absolute index bits outside the tile that must be 1 (0xFF = unused)
-  uint16_t mat;            // first entry in TileArgs::mat
-  uint16_t count;          // group header: gates in the group
-  uint32_t pad;
+  uint8_t j0, j1;          // register bit indices (0 .. kGroupBits-1); group header: s0, s1
+  uint8_t reg_mask;        // register bits that must be 1 (controls / phase bits inside the group);
+                           // group header: s2
+  uint16_t blk_mask;       // tile bits outside the group that must be 1
+  uint16_t count;          // group header: entries in the group (gates + padding)
+  uint64_t outer_mask;     // absolute index bits outside the tile that must be 1
 };
 
 struct TileArgs {
@@ -726,8 +726,15 @@ __device__ __forceinline__ void reg_dense2(double2 (&x)[kGroupAmps], const doubl
 constexpr int kTileThreads = QSIM_TILE_THREADS;
 constexpr int kTileThreadBits = kTileThreads == 64 ? 6 : (kTileThreads == 128 ? 7 : (kTileThreads == 256 ? 8 : (kTileThreads == 512 ? 9 : 10)));
 
+// min waves per SIMD asked of the register allocator: what the LDS footprint admits, capped at 4
+// (5 forces spills at T = 11 and measured slower)
+constexpr int tile_waves(int T) {
+  return (160 * 1024) / ((1 << T) * 16) * (kTileThreads / 64) / 4 > 4 ? 4
+         : ((160 * 1024) / ((1 << T) * 16) * (kTileThreads / 64) / 4 < 1 ? 1 : (160 * 1024) / ((1 << T) * 16) * (kTileThreads / 64) / 4);
+}
+
 template <int T, bool PERSIST>
-__global__ __launch_bounds__(kTileThreads) void k_tile(const TileArgs a, const unsigned ntiles) {
+__global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const TileArgs a, const unsigned ntiles) {
   constexpr int N = 1 << T;
   constexpr int LOW = kTileLow;
   constexpr int NH = T - LOW;                         // tile high bits (host guarantees a.nh == NH)
@@ -801,14 +808,13 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const TileArgs a, const u
     for (int q0 = gi; q0 < ge; ++q0) {
       const int q = __builtin_amdgcn_readfirstlane(q0);
       const TileGate g = a.g[q];
-      if (g.outer0 != 0xFF && !((base >> g.outer0) & 1)) continue;
-      if (g.outer1 != 0xFF && !((base >> g.outer1) & 1)) continue;
-      const double2* m = a.mat + g.mat;
+      const double2* m = a.mat + 4 * q;               // fixed stride: load independent of g
+      if ((base & g.outer_mask) != g.outer_mask) continue;
       const unsigned rm = g.reg_mask;
+      const unsigned bm = g.blk_mask;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        if (g.blk0 != 0xFF && !((tb[b] >> g.blk0) & 1)) continue;
-        if (g.blk1 != 0xFF && !((tb[b] >> g.blk1) & 1)) continue;
+        if ((tb[b] & bm) != bm) continue;
         switch (g.kind) {
           case TG_DENSE1:
             if (g.j0 == 0) reg_dense1<0>(x[b], m, rm); else if (g.j0 == 1) reg_dense1<1>(x[b], m, rm); else reg_dense1<2>(x[b], m, rm);
@@ -826,6 +832,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(const TileArgs a, const u
               if ((i & rm) == rm) x[b][i] = cmul(d, x[b][i]);
             break;
           }
+          case TG_NOP:
+            break;
           default: {
             const int key = g.j0 * 3 + g.j1;
             if (key == 1) reg_dense2<0, 1>(x[b], m); else if (key == 2) reg_dense2<0, 2>(x[b], m);
@@ -992,15 +1000,15 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
     for (size_t j = 0; j < high.size(); ++j) if (high[j] == b) return low + (int)j;
     return -1;
   };
+  auto entries_of = [](const FusedOp& o) { return o.kind == TG_DENSE2 ? 4 : 1; };   // a 4x4 = 4 matrix entries
   std::vector<char> done(members.size(), 0);
   size_t left = members.size();
-  int mat = 0;
   a->ngates = 0;
   while (left) {
     std::vector<int> S;               // tile bits of this group
     std::vector<size_t> grp;          // indices into members
     u64 blocked = 0;
-    int mat_need = 0;
+    int entries = 0;
     for (size_t mi = 0; mi < members.size(); ++mi) {
       if (done[mi]) continue;
       const FusedOp& o = ops[members[mi]];
@@ -1013,13 +1021,12 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
           if (std::find(S.begin(), S.end(), p) == S.end()) need[nneed++] = p;
         }
         if ((int)S.size() + nneed > kGroupBits) ok = false;
-        if (a->ngates + 1 + (int)grp.size() + 1 > kTileMaxGates) ok = false;
-        if (mat + mat_need + o.nm > kTileMaxMat) ok = false;
+        if (a->ngates + 1 + entries + entries_of(o) > kTileMaxGates) ok = false;
       }
       if (!ok) { blocked |= qm; continue; }
       for (int t = 0; t < nneed; ++t) S.push_back(need[t]);
       grp.push_back(mi);
-      mat_need += o.nm;
+      entries += entries_of(o);
     }
     if (grp.empty()) break;           // argument budget exhausted: the rest waits for the next launch
     // pad the group with the highest unused tile bits (high bits keep LDS accesses contiguous)
@@ -1031,25 +1038,21 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
       return -1;
     };
     TileGate hd;
-    std::memset(&hd, 0xFF, sizeof hd);
-    hd.kind = TG_GROUP; hd.j0 = (uint8_t)S[0]; hd.j1 = (uint8_t)S[1]; hd.reg_mask = (uint8_t)S[2]; hd.mat = 0;
-    hd.count = (uint16_t)grp.size();
+    std::memset(&hd, 0, sizeof hd);
+    hd.kind = TG_GROUP; hd.j0 = (uint8_t)S[0]; hd.j1 = (uint8_t)S[1]; hd.reg_mask = (uint8_t)S[2];
+    hd.count = (uint16_t)entries;
     a->g[a->ngates++] = hd;
     for (size_t mi : grp) {
       const FusedOp& o = ops[members[mi]];
       TileGate g;
-      std::memset(&g, 0xFF, sizeof g);
+      std::memset(&g, 0, sizeof g);
       g.kind = (uint8_t)o.kind;
-      g.j0 = g.j1 = 0;
-      g.reg_mask = 0;
-      g.mat = (uint16_t)mat;
-      int nblk = 0, nouter = 0;
       auto require_one = [&](int qubit) {      // a control / phase bit
         const int p = tile_pos(qubit);
-        if (p < 0) { (nouter++ == 0 ? g.outer0 : g.outer1) = (uint8_t)qubit; return; }
+        if (p < 0) { g.outer_mask |= 1ull << qubit; return; }
         const int r = reg_pos(p);
         if (r >= 0) g.reg_mask |= (uint8_t)(1u << r);
-        else (nblk++ == 0 ? g.blk0 : g.blk1) = (uint8_t)p;
+        else g.blk_mask |= (uint16_t)(1u << p);
       };
       if (o.kind == TG_PHASE) {
         for (int t = 0; t < o.nbits; ++t) require_one(o.bits[t]);
@@ -1060,9 +1063,15 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
         g.j0 = (uint8_t)reg_pos(tile_pos(o.target[0]));
         if (o.control >= 0) require_one(o.control);
       }
-      for (int e = 0; e < o.nm; ++e) a->mat[mat + e] = o.m[e];
-      mat += o.nm;
+      const int q = a->ngates;
+      for (int e = 0; e < o.nm; ++e) a->mat[4 * q + e] = o.m[e];
       a->g[a->ngates++] = g;
+      for (int pad = 1; pad < entries_of(o); ++pad) {
+        TileGate nop;
+        std::memset(&nop, 0, sizeof nop);
+        nop.kind = TG_NOP;
+        a->g[a->ngates++] = nop;
+      }
       done[mi] = 1;
       (*emitted)[mi] = 1;
       --left;
