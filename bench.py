@@ -45,7 +45,8 @@ def parse_args():
                     help="fused: planner passes (batch_levels + tile fusion); per-gate: one launch per gate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--sweep", action="store_true", help="also run the 30-qubit per-target H sweep (config 3)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the per-target H sweep (config 3)")
+    ap.add_argument("--sweep-qubits", type=int, default=30)
     return ap.parse_args()
 
 
@@ -168,14 +169,22 @@ def main():
     dom = max(prof, key=lambda e: e["total_ms"]) if prof else None
     roofline = None
     if dom:
-        achieved = dom["algorithmic_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
+        secs = dom["total_ms"] * 1e-3
+        achieved = dom["algorithmic_bytes"] / secs / 1e9
+        moved = dom["hbm_bytes"] / secs / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": pmc_traffic_per_launch(dom["kernel"].split(" ")[0]),
                     "kernel": dom["kernel"], "launches": dom["launches"],
                     "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4),
-                    "algorithmic_bytes_per_launch": dom["algorithmic_bytes"] / dom["launches"]}
-    total_alg = sum(e["algorithmic_bytes"] for e in prof)
+                    "algorithmic_bytes_per_launch": dom["algorithmic_bytes"] / dom["launches"],
+                    "hbm_bytes_moved_per_launch": dom["hbm_bytes"] / dom["launches"],
+                    "hbm_GBps_moved": round(moved, 1), "hbm_frac_moved": round(moved / HBM_PEAK_GBS, 4),
+                    "note": "achieved = algorithmic bytes (SURVEY 8d, summed over the gate-applications a "
+                            "launch performs) / HIP-event time; a fused pass applies many gates per HBM "
+                            "round trip, so achieved may exceed the physical peak; hbm_*_moved is what "
+                            "the launch itself reads+writes (32 B per amplitude)"}
+    total_moved = sum(e["hbm_bytes"] for e in prof)
     out = {
         "metric": "gate-applications/sec (random 1q+CX circuit, complex128 statevector)",
         "value": round(value, 2), "unit": "gate-applications/s",
@@ -189,13 +198,17 @@ def main():
                    "hbm_passes_per_step": engine.passes_per_step(plan),
                    "unit_note": "value = shard-level gate applications (gate x rank) per second"},
         "global_gate_apps_per_s": round(n_gates * args.steps / dt, 2),
-        "achieved_hbm_GBps_all_kernels": round(total_alg * world / dt / 1e9, 1),
+        "hbm_GBps_moved_all_kernels_per_gpu": round(total_moved / dt / 1e9, 1),
         "norm2_after": norm2,
         "roofline": roofline,
         "kernel_breakdown": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof],
     }
-    if args.sweep and world == 1:
-        out["sweep30"] = engine.sweep_1q(30)
+    if world > 1:
+        out["xgmi"] = engine.comm_stats()
+    if not args.no_sweep and world == 1:
+        # BASELINE config 3 / north-star target: H on every target of a 30-qubit state, per-gate
+        # kernels (no fusion across the timed gates), fraction of the 8 TB/s peak per target
+        out["sweep30"] = engine.sweep_1q(args.sweep_qubits)
     if not args.no_cpu_baseline and world == 1:
         base, psi_cpu, done = cpu_baseline(circuit, args.cpu_seconds)
         out["cpu_baseline"] = base

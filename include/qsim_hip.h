@@ -119,13 +119,16 @@ int qsim_time_end(qsim_chunk* c, float* elapsed_ms);       /* record + synchroni
 /* ---- per-launch timing for roofline reports (bench.py) ------------------------------- */
 /* Between begin and end every gate kernel launched on c's stream is bracketed by HIP events
  * (no synchronisation, no extra kernels).  qsim_profile_end synchronises the stream and
- * returns, per kernel class, the launch count, the summed event time and the summed
- * algorithmic bytes (32 B per amplitude a launch reads and writes).           */
+ * returns, per kernel class, the launch count, the summed event time, the summed
+ * algorithmic bytes (per gate-application 32 B per amplitude the gate touches,
+ * summed over the gates of a launch -- a fused pass counts every gate it applies) and
+ * hbm_bytes, the bytes the launches themselves had to move (32 B per amplitude touched once). */
 typedef struct {
   char kernel[48];
   uint64_t launches;
   double total_ms;
   double algorithmic_bytes;
+  double hbm_bytes;
 } qsim_profile_entry;
 int qsim_profile_begin(qsim_chunk* c);
 int qsim_profile_end(qsim_chunk* c, int max_entries, int* n_entries, qsim_profile_entry* out);

@@ -73,7 +73,8 @@ SIGNATURES = {
 
 class ProfileEntry(C.Structure):
     _fields_ = [("kernel", C.c_char * 48), ("launches", C.c_uint64),
-                ("total_ms", C.c_double), ("algorithmic_bytes", C.c_double)]
+                ("total_ms", C.c_double), ("algorithmic_bytes", C.c_double),
+                ("hbm_bytes", C.c_double)]
 
 _lib = None
 

@@ -132,13 +132,22 @@ __device__ __forceinline__ u64 expand_index(u64 c, int npos, int p0, int p1, int
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one).  With SWZ
 // each XCD walks one contiguous eighth of the work-item space instead of every eighth block.
+// (2-D grids only carry block counts whose x extent would overflow the 2^32 work-item limit of one
+// grid dimension -- 33-qubit chunks; the linear id is y * gridDim.x + x.)
 template <bool SWZ>
 __device__ __forceinline__ u64 logical_block() {
+  const u64 bid = (u64)blockIdx.y * gridDim.x + blockIdx.x;
   if (SWZ) {
-    const u64 per_xcd = gridDim.x >> 3;
-    return (u64)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const u64 per_xcd = ((u64)gridDim.x * gridDim.y) >> 3;
+    return (bid & 7) * per_xcd + (bid >> 3);
   }
-  return blockIdx.x;
+  return bid;
+}
+
+constexpr unsigned kMaxGridX = 1u << 22;   // x * 256 threads stays below 2^32 work-items
+static dim3 grid_for(u64 blocks) {
+  if (blocks <= kMaxGridX) return dim3((unsigned)blocks);
+  return dim3(kMaxGridX, (unsigned)((blocks + kMaxGridX - 1) / kMaxGridX));
 }
 
 template <int NM>
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void k_gate_shuffle(const ShuffleArgs<NMR, 
         coef[r][r2][d] = c;
       }
   }
-  const u64 first = ((u64)blockIdx.x * ITEMS) * kBlock + threadIdx.x;
+  const u64 first = (logical_block<false>() * ITEMS) * kBlock + threadIdx.x;
   u64 idx[ITEMS];
   bool live[ITEMS];
   double2 x[ITEMS][NMR];
@@ -336,7 +345,8 @@ static const Tuning& tuning() {
 // qsim_profile_end.
 struct LaunchRecord {
   int cls;            // kernel class id
-  double bytes;       // algorithmic bytes: 32 B per amplitude touched
+  double bytes;       // algorithmic bytes: sum over the launch's gate-applications
+  double hbm_bytes;   // bytes the launch itself has to move (32 B per amplitude it touches)
   hipEvent_t e0, e1;
 };
 struct ProfileState {
@@ -366,11 +376,12 @@ static hipEvent_t prof_event() {
 struct ProfileScope {  // RAII around one launch
   bool on;
   LaunchRecord rec;
-  ProfileScope(int cls, double bytes, hipStream_t stream) {
+  ProfileScope(int cls, double bytes, hipStream_t stream, double hbm_bytes = -1.0) {
     on = g_prof.open && g_prof.stream == stream;
     if (!on) return;
     rec.cls = cls;
     rec.bytes = bytes;
+    rec.hbm_bytes = hbm_bytes < 0 ? bytes : hbm_bytes;
     rec.e0 = prof_event();
     rec.e1 = prof_event();
     (void)hipEventRecord(rec.e0, stream);
@@ -459,7 +470,7 @@ static int launch_reg(const Plan& p, hipStream_t stream) {
   const u64 per_block = (u64)kBlock * ITEMS;
   const u64 blocks = (p.count + per_block - 1) / per_block;
   ProfileScope prof(NM == 1 ? 0 : (NM == 2 ? 1 : 2), 32.0 * NM * (double)p.count, stream);
-  hipLaunchKernelGGL((k_gate<NM, ITEMS, NT, SWZ>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, a);
+  hipLaunchKernelGGL((k_gate<NM, ITEMS, NT, SWZ>), grid_for(blocks), dim3(kBlock), 0, stream, a);
   prof.done(stream);
   HIP_TRY(hipGetLastError());
   return QSIM_OK;
@@ -479,7 +490,7 @@ static int launch_shuffle(const Plan& p, hipStream_t stream) {
   const u64 per_block = (u64)kBlock * ITEMS;
   const u64 blocks = (p.count + per_block - 1) / per_block;
   ProfileScope prof(NMR == 2 ? 5 : (NSH == 1 ? 3 : 4), 32.0 * NMR * (double)p.count, stream);
-  hipLaunchKernelGGL((k_gate_shuffle<NMR, NSH, ITEMS, NT>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, a);
+  hipLaunchKernelGGL((k_gate_shuffle<NMR, NSH, ITEMS, NT>), grid_for(blocks), dim3(kBlock), 0, stream, a);
   prof.done(stream);
   HIP_TRY(hipGetLastError());
   return QSIM_OK;
@@ -505,7 +516,7 @@ static int launch_plan(const Plan& p, hipStream_t stream) {
   // NT only when every wave instruction covers whole 128-B lines
   bool nt = p.low_removed >= 3;
   if (t.force_nt >= 0) nt = t.force_nt != 0;
-  if (p.count > (0x7fffffffull * kBlock)) return fail(QSIM_ERR_INVALID, "grid too large");
+  if (p.count > (1ull << 40)) return fail(QSIM_ERR_INVALID, "grid too large");
   if (p.nsh > 0) {
     if (p.nm == 1 && p.nsh == 1) return nt ? launch_shuffle<1, 1, 2, true>(p, stream) : launch_shuffle<1, 1, 2, false>(p, stream);
     if (p.nm == 1 && p.nsh == 2) return nt ? launch_shuffle<1, 2, 2, true>(p, stream) : launch_shuffle<1, 2, 2, false>(p, stream);
@@ -881,6 +892,7 @@ struct FusedOp {
   int nq;
   double2 m[16];
   int nm;              // matrix entries (4, 1 or 16)
+  int halvings;        // algorithmic bytes = 32 B x 2^(k - halvings)  
 };
 
 static void set_1q_kind(FusedOp* o) {   // o->m holds the 2x2
@@ -897,6 +909,7 @@ static bool classify_op(int nq, const int32_t* q, const double* U, FusedOp* o) {
   o->control = -1;
   o->nbits = 0;
   o->ntargets = 0;
+  o->halvings = 0;
   auto C = [&](int i) { return make_double2(U[2 * i], U[2 * i + 1]); };
   if (nq == 1) {
     const bool diag = is_zero(U[2], U[3]) && is_zero(U[4], U[5]);
@@ -944,13 +957,16 @@ static bool classify_op(int nq, const int32_t* q, const double* U, FusedOp* o) {
   o->kind = TG_DENSE2; o->target[0] = q[0]; o->target[1] = q[1]; o->ntargets = 2;
   for (int i = 0; i < 16; ++i) o->m[i] = C(i);
   o->nm = 16;
+  const bool swap = one(0, 0) && one(3, 3) && one(1, 2) && one(2, 1) && z(1, 1) && z(2, 2) && z(0, 1) && z(0, 2) &&
+                    z(0, 3) && z(1, 0) && z(1, 3) && z(2, 0) && z(2, 3) && z(3, 0) && z(3, 1) && z(3, 2);
+  o->halvings = swap ? 1 : 0;   // SWAP only exchanges |01> and |10>
   return true;
 }
 
 template <int T>
-static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t stream) {
+static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t stream, double alg_bytes) {
   const u64 ntiles = 1ull << (c->k - T);
-  ProfileScope prof(6, 32.0 * (double)amps(c), stream);
+  ProfileScope prof(6, alg_bytes, stream, 32.0 * (double)amps(c));
   if (tuning().tile_persistent) {
     // persistent grid: as many workgroups as stay resident, each walks tiles b, b + grid, ...
     static int resident = 0;
@@ -970,13 +986,13 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   return QSIM_OK;
 }
 
-static int launch_tile_any(const TileArgs& a, int T, const qsim_chunk* c, hipStream_t stream) {
+static int launch_tile_any(const TileArgs& a, int T, const qsim_chunk* c, hipStream_t stream, double alg_bytes) {
   switch (T) {
-    case 8: return launch_tile<8>(a, c, stream);
-    case 9: return launch_tile<9>(a, c, stream);
-    case 10: return launch_tile<10>(a, c, stream);
-    case 11: return launch_tile<11>(a, c, stream);
-    case 12: return launch_tile<12>(a, c, stream);
+    case 8: return launch_tile<8>(a, c, stream, alg_bytes);
+    case 9: return launch_tile<9>(a, c, stream, alg_bytes);
+    case 10: return launch_tile<10>(a, c, stream, alg_bytes);
+    case 11: return launch_tile<11>(a, c, stream, alg_bytes);
+    case 12: return launch_tile<12>(a, c, stream, alg_bytes);
   }
   return fail(QSIM_ERR_INVALID, "internal: tile size %d", T);
 }
@@ -1127,11 +1143,17 @@ static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_pass
     std::vector<char> emitted(members.size(), 0);
     emit_groups(ops, members, high, T, &a, &emitted);
     size_t n_emitted = 0;
+    double alg_bytes = 0;   // dense 32N, diagonal / controlled / SWAP 16N, CZ/CR 8N
     for (size_t mi = 0; mi < members.size(); ++mi)
-      if (emitted[mi]) { done[members[mi]] = 1; --remaining; ++n_emitted; }
+      if (emitted[mi]) {
+        const FusedOp& o = ops[members[mi]];
+        const int halvings = o.kind == TG_PHASE ? o.nbits : (o.control >= 0 ? 1 : o.halvings);
+        alg_bytes += 32.0 * (double)(amps(c) >> halvings);
+        done[members[mi]] = 1; --remaining; ++n_emitted;
+      }
     if (!n_emitted) return fail(QSIM_ERR_INVALID, "internal: fused planner emitted nothing");
     if (tune.debug_skip_gates) a.ngates = 0;       // profiling aid: load -> LDS -> store only
-    int rc = launch_tile_any(a, T, c, c->stream);
+    int rc = launch_tile_any(a, T, c, c->stream, alg_bytes);
     if (rc) return rc;
     ++*n_passes;
   }
@@ -1736,13 +1758,14 @@ int qsim_profile_end(qsim_chunk* c, int max_entries, int* n_entries, qsim_profil
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
   uint64_t launches[kNumClasses] = {0};
-  double ms[kNumClasses] = {0}, bytes[kNumClasses] = {0};
+  double ms[kNumClasses] = {0}, bytes[kNumClasses] = {0}, hbm[kNumClasses] = {0};
   for (LaunchRecord& r : g_prof.records) {
     float t = 0.f;
     HIP_TRY(hipEventElapsedTime(&t, r.e0, r.e1));
     launches[r.cls] += 1;
     ms[r.cls] += t;
     bytes[r.cls] += r.bytes;
+    hbm[r.cls] += r.hbm_bytes;
     g_prof.pool.push_back(r.e0);
     g_prof.pool.push_back(r.e1);
   }
@@ -1755,6 +1778,7 @@ int qsim_profile_end(qsim_chunk* c, int max_entries, int* n_entries, qsim_profil
       out[n].launches = launches[cls];
       out[n].total_ms = ms[cls];
       out[n].algorithmic_bytes = bytes[cls];
+      out[n].hbm_bytes = hbm[cls];
     }
     ++n;
   }

@@ -175,7 +175,8 @@ class DeviceChunk:
         out = []
         for e in entries[: min(n.value, 16)]:
             out.append({"kernel": e.kernel.decode(), "launches": int(e.launches),
-                        "total_ms": float(e.total_ms), "algorithmic_bytes": float(e.algorithmic_bytes)})
+                        "total_ms": float(e.total_ms), "algorithmic_bytes": float(e.algorithmic_bytes),
+                        "hbm_bytes": float(e.hbm_bytes)})
         return out
 
     def pack_half(self, bit: int, value: int, buf: "DeviceChunk") -> None:

@@ -155,9 +155,14 @@ class DistributedEngine:
         if self.k < 0:
             raise ValueError("more ranks than amplitudes")
         self.mode, self.staging, self.staging_method = mode, staging, staging_method
+        if backend is None:
+            torch.cuda.set_device(local_rank)     # before RCCL initialises: one rank <-> one GPU
         if init_process_group and not dist.is_initialized():
-            use_gpu = backend is None
-            dist.init_process_group("nccl" if use_gpu else "gloo", rank=rank, world_size=world)
+            if backend is None:
+                dist.init_process_group("nccl", rank=rank, world_size=world,
+                                        device_id=torch.device(f"cuda:{local_rank}"))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         self.backend = backend if backend is not None else HipShardBackend(self.k, local_rank)
         self.l2p = list(range(n_qubits))      # logical qubit -> physical index bit
         self.xgmi_bytes_sent = 0
@@ -407,6 +412,9 @@ class DistributedEngine:
 
     def profile_end(self):
         return self.backend.profile_end() if hasattr(self.backend, "profile_end") else []
+
+    def comm_stats(self) -> dict:
+        return {"bytes_sent_per_rank": self.xgmi_bytes_sent, "exchanges": self.exchanges}
 
     def close(self) -> None:
         self.backend.close()

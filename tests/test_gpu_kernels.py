@@ -326,3 +326,48 @@ def test_fused_pass_counts_and_layer_structure(hip):
     np.testing.assert_allclose(d12.download(), want, rtol=0, atol=1e-13)
     d12.close()
     dev.close()
+
+
+# ---------------------------------------------------------------- full-size closed-form checks
+def test_ghz_qft_30q_fused_closed_form(hip):
+    """BASELINE config-5 circuit family at one GPU's share (30 qubits, 16 GiB, 495 gates, fused
+    passes): every amplitude within 1e-10 of 2^-(n+1)/2 (1 + exp(-2 pi i y / 2^n)), evaluated
+    on the device over all 2^30 indices, plus a host-side sample."""
+    from quantum_simulations_amd.circuit.io import validate_circuit_dict
+    from quantum_simulations_amd.circuits import generate_ghz_qft
+    from quantum_simulations_amd.runner.engine import gate_ops
+    n = 30
+    dev = hip.DeviceChunk.zero_state(n)
+    passes = dev.apply_ops(gate_ops(validate_circuit_dict(generate_ghz_qft(n))))
+    assert passes < 200
+    assert dev.max_abs_err_closed_form("ghz_qft", n) < ATOL_CIRCUIT
+    assert abs(dev.norm2() - 1.0) < 1e-12
+    for off in (0, (1 << 29) + 12345, (1 << n) - 4096):
+        got = dev.download(off, 4096)
+        want = orc.ghz_qft_closed_form(n, np.arange(off, off + 4096))
+        np.testing.assert_allclose(got, want, rtol=0, atol=ATOL_CIRCUIT)
+    dev.close()
+
+
+def test_ghz_33q_single_gpu_64bit_indexing(hip):
+    """33 qubits = 2^33 amplitudes = 128 GiB on ONE MI355X (the size 8 GPUs share in BASELINE
+    config 5): GHZ ladder, gate by gate and fused, checked against the closed form on-device;
+    exercises 64-bit index arithmetic and 2^23-block grids."""
+    from quantum_simulations_amd.circuit.io import validate_circuit_dict
+    from quantum_simulations_amd.circuits import generate_ghz_circuit
+    from quantum_simulations_amd.runner.engine import gate_ops
+    n = 33
+    try:
+        dev = hip.DeviceChunk.zero_state(n)
+    except MemoryError:
+        pytest.skip("device has less than 128 GiB free")
+    ops = gate_ops(validate_circuit_dict(generate_ghz_circuit(n)))
+    dev.apply_ops(ops, fused=False)
+    assert dev.max_abs_err_closed_form("ghz", n) < ATOL_CIRCUIT
+    assert abs(dev.norm2() - 1.0) < 1e-12
+    dev.init_zero(True)
+    dev.apply_ops(ops, fused=True)
+    assert dev.max_abs_err_closed_form("ghz", n) < ATOL_CIRCUIT
+    tail = dev.download((1 << n) - 2, 2)
+    assert abs(tail[1] - 2 ** -0.5) < 1e-12 and tail[0] == 0
+    dev.close()
