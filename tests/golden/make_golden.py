@@ -18,6 +18,7 @@ Fixture groups:
                          permute_state / non_insular_qubits outputs
   G5 v1_sql.npz          v1 SQL engine final states (== G2) + row counts
   G6 chunked_c64.npz     single_node.run(chunk_size=2|4) complex64 results
+  G7 chunk_files.json    a buffer directory written by the reference block store
 """
 from __future__ import annotations
 
@@ -384,6 +385,35 @@ def make_chunked():
     return len(cases)
 
 
+# ------------------------------------------------------------------------------ G7
+def make_chunk_files():
+    """A buffer directory written by the reference's own block store (chunk bytes + manifest),
+    and the vector its collect_state reads back, for a seeded 5-qubit state in 4 chunks."""
+    import base64
+    from wenbo_engine.storage import block_store as ref_bs
+    from wenbo_engine.storage.manifest import Manifest, write_manifest_atomic
+    rng = np.random.default_rng(77)
+    psi = (rng.standard_normal(32) + 1j * rng.standard_normal(32)).astype(np.complex128)
+    psi /= np.linalg.norm(psi)
+    doc = {"state_in": cplx_list(psi), "chunk_size": 8}
+    with tempfile.TemporaryDirectory() as td:
+        buf = Path(td) / "state_a"
+        names = []
+        for c in range(4):
+            name = ref_bs.chunk_filename(c)
+            ref_bs.write_chunk_atomic(buf / "chunks" / name, psi[c * 8:(c + 1) * 8])
+            names.append(name)
+        write_manifest_atomic(buf, Manifest(n_qubits=5, chunk_size=8, n_chunks=4, chunks=names))
+        doc["chunks"] = {n: base64.b64encode((buf / "chunks" / n).read_bytes()).decode() for n in names}
+        m = json.loads((buf / "manifest.json").read_text())
+        m.pop("created")
+        doc["manifest"] = m
+        doc["collected"] = cplx_list(ref_runner.collect_state(buf))
+    with open(HERE / "chunk_files.json", "w") as f:
+        json.dump(doc, f)
+    return 1
+
+
 if __name__ == "__main__":
     print("G1 gate matrices:", make_gate_matrices())
     print("G2 states:", make_states())
@@ -391,3 +421,4 @@ if __name__ == "__main__":
     print("G4 planner cases:", make_planner())
     print("G5 v1 SQL cases:", make_v1())
     print("G6 chunked cases:", make_chunked())
+    print("G7 chunk-file case:", make_chunk_files())

@@ -1,0 +1,68 @@
+"""Reference-compatible chunk files: this build's writer produces the same
+bytes and manifest as the reference's block store (tests/golden/chunk_files.json, written by the
+reference), and its reader returns what the reference's collect_state returns."""
+import base64
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from quantum_simulations_amd.storage import block_store
+from tests.golden_io import c128, jdoc
+
+
+def test_writer_matches_reference_bytes(tmp_path):
+    g = jdoc("chunk_files.json")
+    psi = c128(g["state_in"])
+    buf = block_store.write_state(tmp_path / "state_a", psi, chunk_size=g["chunk_size"])
+    for name, b64 in g["chunks"].items():
+        assert (buf / "chunks" / name).read_bytes() == base64.b64decode(b64), name
+    m = json.loads((buf / "manifest.json").read_text())
+    assert isinstance(m.pop("created"), float)
+    assert m == g["manifest"]
+    np.testing.assert_array_equal(block_store.read_state(buf), c128(g["collected"]))
+
+
+def test_reader_accepts_reference_directory(tmp_path):
+    g = jdoc("chunk_files.json")
+    d = tmp_path / "ref_buf"
+    (d / "chunks").mkdir(parents=True)
+    for name, b64 in g["chunks"].items():
+        (d / "chunks" / name).write_bytes(base64.b64decode(b64))
+    (d / "manifest.json").write_text(json.dumps({**g["manifest"], "created": 1.0}))
+    np.testing.assert_array_equal(block_store.read_state(d), c128(g["collected"]))
+
+
+def test_mapping_file_and_validation(tmp_path):
+    psi = np.zeros(16, dtype=np.complex128)
+    psi[3] = 1
+    block_store.write_state(tmp_path / "b", psi, chunk_size=4, log_to_phys=[1, 0, 2, 3], work_dir=tmp_path)
+    assert json.loads((tmp_path / "qubit_mapping.json").read_text()) == [1, 0, 2, 3]
+    with pytest.raises(ValueError, match="divisible by chunk_size"):
+        block_store.write_state(tmp_path / "c", psi, chunk_size=3)
+    bad = tmp_path / "bad"
+    (bad / "chunks").mkdir(parents=True)
+    (bad / "manifest.json").write_text(json.dumps(
+        {"n_qubits": 4, "chunk_size": 4, "n_chunks": 3, "dtype": "complex64", "chunks": ["a", "b", "c"]}))
+    with pytest.raises(ValueError, match="2\\^n_qubits"):
+        block_store.read_manifest(bad)
+
+
+@pytest.mark.gpu
+def test_gpu_run_exports_reference_format(tmp_path):
+    from quantum_simulations_amd.circuits import generate_qft_circuit
+    from quantum_simulations_amd.runner import single_node
+    from oracle import dense_oracle as orc
+    cd = generate_qft_circuit(8)
+    buf = single_node.run(cd, tmp_path, chunk_size=32, use_staging=True)
+    out = block_store.write_state(tmp_path / "state_b", buf, chunk_size=32)
+    assert len(list((out / "chunks").glob("chunk_*.bin"))) == 8
+    stored = block_store.read_state(out)
+    from quantum_simulations_amd.circuit.staging import permute_state
+    mapping = json.loads((tmp_path / "qubit_mapping.json").read_text()) if (tmp_path / "qubit_mapping.json").exists() else list(range(8))
+    np.testing.assert_allclose(permute_state(stored, mapping), orc.simulate(cd), atol=1e-6)
+    dev = block_store.load_to_device(out)
+    np.testing.assert_allclose(dev.download(), stored, atol=0)
+    dev.close()
+    buf.close()
