@@ -320,9 +320,13 @@ struct Tuning {
   int tile_wgs_per_cu = 8;   // upper bound; the occupancy query decides
   int num_cus = 256;
   int debug_skip_gates = 0;  // QSIM_DEBUG_SKIP_GATES=1: tile passes move data but apply nothing (WRONG results)
+  int tile_special = 1;      // real / Y-like / -1 / +-i special-case opcodes
+  int tile_opcode = 1;       // opcode-dispatched gate loop (k_tile_op) where one block per thread fits
   int tile_persistent = 0;   // r01: one-shot grid (5 WGs/CU) beats the persistent prefetching form (3 WGs/CU)
   Tuning() {
     if (const char* e = getenv("QSIM_TILE_PERSIST")) tile_persistent = atoi(e);
+    if (const char* e = getenv("QSIM_TILE_OPCODE")) tile_opcode = atoi(e);
+    if (const char* e = getenv("QSIM_TILE_SPECIAL")) tile_special = atoi(e);
     if (const char* e = getenv("QSIM_DEBUG_SKIP_GATES")) debug_skip_gates = atoi(e);
     if (const char* e = getenv("QSIM_TILE_WGS")) tile_wgs_per_cu = std::max(1, atoi(e));
     hipDeviceProp_t prop;
@@ -656,7 +660,8 @@ struct alignas(16) TileGate {   // 16 bytes: one s_load_dwordx4; predicates are 
   uint8_t reg_mask;        // register bits that must be 1 (controls / phase bits inside the group);
                            // group header: s2
   uint16_t blk_mask;       // tile bits outside the group that must be 1
-  uint16_t count;          // group header: entries in the group (gates + padding)
+  uint8_t count;           // group header: entries in the group (gates + padding)
+  uint8_t opcode;          // pre-decoded (kind, register target, register control) for k_tile_op
   uint64_t outer_mask;     // absolute index bits outside the tile that must be 1
 };
 
@@ -880,6 +885,168 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
   }  // persistent tile loop (each thread re-writes only the LDS slots it just read: no barrier)
 }
 
+// ---- k_tile_op: the same tile pass with an opcode-dispatched gate loop --------------------------
+// One register block (8 named amplitudes x0..x7) per thread; every (kind, register target,
+// register control) combination is its own straight-line case selected by ONE opcode byte the
+// host computed, so a gate costs a descriptor load, two mask tests, one switch and the math --
+// no per-pair control tests, no bit-field decoding (the generic k_tile loop spends ~75 scalar
+// instructions per gate and wave on those; the CU has a single scalar unit).
+enum : uint8_t {
+  OPC_NOP = 0,
+  OPC_DENSE1 = 1,     // +0..8: variants below
+  OPC_SWAP1 = 10,     // +0..8
+  OPC_ANTI1 = 19,     // +0..8
+  OPC_PHASE = 28,     // +register mask 0..7
+  OPC_DENSE2 = 36,    // +3*JA + JB
+  OPC_REAL1 = 45,     // +0..8: 2x2 with real entries (H, RY, G, real products): half the multiplies
+  OPC_YLIKE1 = 54,    // +0..8: [[0,-i],[i,0]] (Y, CY): swaps and sign flips only
+  OPC_PHASE_NEG = 63, // +mask: multiply by -1 (Z, CZ)
+  OPC_PHASE_I = 71,   // +mask: multiply by +i (S)
+  OPC_PHASE_NI = 79   // +mask: multiply by -i
+};
+// 1q variant: 0..2 = target bit J without register control; 3 + 2*J + k = control on the k-th of
+// the two other register bits (ascending)
+static inline int opc_1q_variant(int J, int C) {
+  return C < 0 ? J : 3 + 2 * J + ((C > J ? C - 1 : C) == 0 ? 0 : 1);
+}
+
+#define QS_D1(A, B) { const double2 a_ = A, b_ = B; A = cfma(u01, b_, cmul(u00, a_)); B = cfma(u11, b_, cmul(u10, a_)); }
+#define QS_AN(A, B) { const double2 a_ = A, b_ = B; A = cmul(u01, b_); B = cmul(u10, a_); }
+#define QS_SW(A, B) { const double2 t_ = A; A = B; B = t_; }
+#define QS_PH(A) { A = cmul(u00, A); }
+#define QS_DR(A, B) { const double2 a_ = A, b_ = B;                                               \
+    A = make_double2(fma(u01.x, b_.x, u00.x * a_.x), fma(u01.x, b_.y, u00.x * a_.y));               \
+    B = make_double2(fma(u11.x, b_.x, u10.x * a_.x), fma(u11.x, b_.y, u10.x * a_.y)); }
+#define QS_YL(A, B) { const double2 a_ = A, b_ = B; A = make_double2(b_.y, -b_.x); B = make_double2(-a_.y, a_.x); }
+#define QS_PN(A) { A = make_double2(-A.x, -A.y); }
+#define QS_PI(A) { A = make_double2(-A.y, A.x); }
+#define QS_PM(A) { A = make_double2(A.y, -A.x); }
+#define QS_CASES_PHASE(BASE, OP)                                                                  \
+  case BASE + 0: OP(x0) OP(x1) OP(x2) OP(x3) OP(x4) OP(x5) OP(x6) OP(x7) break;                   \
+  case BASE + 1: OP(x1) OP(x3) OP(x5) OP(x7) break;  case BASE + 2: OP(x2) OP(x3) OP(x6) OP(x7) break; \
+  case BASE + 3: OP(x3) OP(x7) break;                case BASE + 4: OP(x4) OP(x5) OP(x6) OP(x7) break; \
+  case BASE + 5: OP(x5) OP(x7) break;                case BASE + 6: OP(x6) OP(x7) break;          \
+  case BASE + 7: OP(x7) break;
+#define QS_PAIRS_0(OP) OP(x0, x1) OP(x2, x3) OP(x4, x5) OP(x6, x7)
+#define QS_PAIRS_1(OP) OP(x0, x2) OP(x1, x3) OP(x4, x6) OP(x5, x7)
+#define QS_PAIRS_2(OP) OP(x0, x4) OP(x1, x5) OP(x2, x6) OP(x3, x7)
+#define QS_PAIRS_3(OP) OP(x2, x3) OP(x6, x7)
+#define QS_PAIRS_4(OP) OP(x4, x5) OP(x6, x7)
+#define QS_PAIRS_5(OP) OP(x1, x3) OP(x5, x7)
+#define QS_PAIRS_6(OP) OP(x4, x6) OP(x5, x7)
+#define QS_PAIRS_7(OP) OP(x1, x5) OP(x3, x7)
+#define QS_PAIRS_8(OP) OP(x2, x6) OP(x3, x7)
+#define QS_CASES_1Q(BASE, OP)                                                             \
+  case BASE + 0: QS_PAIRS_0(OP) break;  case BASE + 1: QS_PAIRS_1(OP) break;             \
+  case BASE + 2: QS_PAIRS_2(OP) break;  case BASE + 3: QS_PAIRS_3(OP) break;             \
+  case BASE + 4: QS_PAIRS_4(OP) break;  case BASE + 5: QS_PAIRS_5(OP) break;             \
+  case BASE + 6: QS_PAIRS_6(OP) break;  case BASE + 7: QS_PAIRS_7(OP) break;             \
+  case BASE + 8: QS_PAIRS_8(OP) break;
+// 4x4 on (v00, v01 = qb set, v10 = qa set, v11); matrix rows from the gate's 16 entries
+#define QS_D2(V0, V1, V2, V3) {                                                                         \
+    const double2 a_ = V0, b_ = V1, c_ = V2, d_ = V3;                                                   \
+    V0 = cfma(a.mat[mq + 3], d_, cfma(a.mat[mq + 2], c_, cfma(a.mat[mq + 1], b_, cmul(a.mat[mq + 0], a_))));     \
+    V1 = cfma(a.mat[mq + 7], d_, cfma(a.mat[mq + 6], c_, cfma(a.mat[mq + 5], b_, cmul(a.mat[mq + 4], a_))));     \
+    V2 = cfma(a.mat[mq + 11], d_, cfma(a.mat[mq + 10], c_, cfma(a.mat[mq + 9], b_, cmul(a.mat[mq + 8], a_))));   \
+    V3 = cfma(a.mat[mq + 15], d_, cfma(a.mat[mq + 14], c_, cfma(a.mat[mq + 13], b_, cmul(a.mat[mq + 12], a_)))); }
+
+template <int T>
+__global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile_op(const TileArgs a, const unsigned ntiles) {
+  constexpr int N = 1 << T;
+  constexpr int LOW = kTileLow;
+  constexpr int NH = T - LOW;
+  constexpr int BLOCK = kTileThreads;
+  constexpr int TB = kTileThreadBits;
+  constexpr int PER = N / BLOCK > 0 ? N / BLOCK : 1;
+  constexpr int NBLK = N >> kGroupBits;
+  static_assert(NBLK <= BLOCK, "k_tile_op keeps one register block per thread");
+  __shared__ double2 lds[N];
+  const int tid = threadIdx.x;
+  const bool elem_ok = N >= BLOCK || tid < N;
+  u64 base = (u64)blockIdx.x << LOW;
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    const int p = a.h[j];
+    base = ((base >> p) << (p + 1)) | (base & ((1ull << p) - 1));
+  }
+  u64 off_tid = tid & ((1 << LOW) - 1);
+#pragma unroll
+  for (int i = 0; i < TB - LOW && i < NH; ++i) off_tid |= (u64)((tid >> (LOW + i)) & 1) << a.h[i];
+  auto off_j = [&](int j) -> u64 {
+    u64 o = 0;
+#pragma unroll
+    for (int i = TB - LOW; i < NH; ++i) o |= (u64)((j >> (i - (TB - LOW))) & 1) << a.h[i];
+    return o;
+  };
+  {
+    double2 v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) if (elem_ok) v[j] = ld_amp<true>(a.amp + base + off_tid + off_j(j));
+#pragma unroll
+    for (int j = 0; j < PER; ++j) if (elem_ok) lds[lds_slot(tid + BLOCK * j)] = v[j];
+  }
+  __syncthreads();
+
+  const bool live = NBLK == BLOCK || tid < NBLK;
+  int gi = 0;
+  while (gi < a.ngates) {
+    gi = __builtin_amdgcn_readfirstlane(gi);
+    const TileGate hd = a.g[gi++];                    // group header
+    const int s0 = hd.j0, s1 = hd.j1, s2 = hd.reg_mask;
+    const int ge = gi + hd.count;
+    const unsigned tb = insert_zero(insert_zero(insert_zero((unsigned)tid, s0), s1), s2);
+    const unsigned b0 = 1u << s0, b1 = 1u << s1, b2 = 1u << s2;
+    double2 x0, x1, x2, x3, x4, x5, x6, x7;
+    if (live) {
+      x0 = lds[lds_slot(tb)];            x1 = lds[lds_slot(tb | b0)];
+      x2 = lds[lds_slot(tb | b1)];       x3 = lds[lds_slot(tb | b1 | b0)];
+      x4 = lds[lds_slot(tb | b2)];       x5 = lds[lds_slot(tb | b2 | b0)];
+      x6 = lds[lds_slot(tb | b2 | b1)];  x7 = lds[lds_slot(tb | b2 | b1 | b0)];
+    }
+    for (int q0 = gi; q0 < ge; ++q0) {
+      const int q = __builtin_amdgcn_readfirstlane(q0);
+      const TileGate g = a.g[q];
+      const int mq = 4 * q;
+      if ((base & g.outer_mask) != g.outer_mask) continue;
+      if (!live || (tb & g.blk_mask) != g.blk_mask) continue;
+      const double2 u00 = a.mat[mq], u01 = a.mat[mq + 1], u10 = a.mat[mq + 2], u11 = a.mat[mq + 3];
+      switch (g.opcode) {
+        QS_CASES_1Q(OPC_DENSE1, QS_D1)
+        QS_CASES_1Q(OPC_SWAP1, QS_SW)
+        QS_CASES_1Q(OPC_ANTI1, QS_AN)
+        QS_CASES_1Q(OPC_REAL1, QS_DR)
+        QS_CASES_1Q(OPC_YLIKE1, QS_YL)
+        QS_CASES_PHASE(OPC_PHASE, QS_PH)
+        QS_CASES_PHASE(OPC_PHASE_NEG, QS_PN)
+        QS_CASES_PHASE(OPC_PHASE_I, QS_PI)
+        QS_CASES_PHASE(OPC_PHASE_NI, QS_PM)
+        case OPC_DENSE2 + 1: QS_D2(x0, x2, x1, x3) QS_D2(x4, x6, x5, x7) break;   // qa = bit 0, qb = bit 1
+        case OPC_DENSE2 + 2: QS_D2(x0, x4, x1, x5) QS_D2(x2, x6, x3, x7) break;   // qa = bit 0, qb = bit 2
+        case OPC_DENSE2 + 3: QS_D2(x0, x1, x2, x3) QS_D2(x4, x5, x6, x7) break;   // qa = bit 1, qb = bit 0
+        case OPC_DENSE2 + 5: QS_D2(x0, x4, x2, x6) QS_D2(x1, x5, x3, x7) break;   // qa = bit 1, qb = bit 2
+        case OPC_DENSE2 + 6: QS_D2(x0, x1, x4, x5) QS_D2(x2, x3, x6, x7) break;   // qa = bit 2, qb = bit 0
+        case OPC_DENSE2 + 7: QS_D2(x0, x2, x4, x6) QS_D2(x1, x3, x5, x7) break;   // qa = bit 2, qb = bit 1
+        default: break;
+      }
+    }
+    if (live) {
+      lds[lds_slot(tb)] = x0;            lds[lds_slot(tb | b0)] = x1;
+      lds[lds_slot(tb | b1)] = x2;       lds[lds_slot(tb | b1 | b0)] = x3;
+      lds[lds_slot(tb | b2)] = x4;       lds[lds_slot(tb | b2 | b0)] = x5;
+      lds[lds_slot(tb | b2 | b1)] = x6;  lds[lds_slot(tb | b2 | b1 | b0)] = x7;
+    }
+    __syncthreads();
+    gi = ge;
+  }
+  {
+    double2 w[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) if (elem_ok) w[j] = lds[lds_slot(tid + BLOCK * j)];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) if (elem_ok) st_amp<true>(a.amp + base + off_tid + off_j(j), w[j]);
+  }
+}
+
 // ---- host planner: op list -> passes -> register groups ----------------------------------------
 struct FusedOp {
   int kind;            // TG_DENSE1 / TG_ANTI1 / TG_SWAP1 (target, optional control), TG_PHASE, TG_DENSE2
@@ -978,6 +1145,11 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
     const int per_cu = std::max(1, std::min(tuning().tile_wgs_per_cu, resident));
     const u64 blocks = std::min<u64>(ntiles, (u64)tuning().num_cus * per_cu);
     hipLaunchKernelGGL((k_tile<T, true>), dim3((unsigned)blocks), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
+  } else if constexpr (((1 << T) >> kGroupBits) <= kTileThreads) {
+    if (tuning().tile_opcode)
+      hipLaunchKernelGGL((k_tile_op<T>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
+    else
+      hipLaunchKernelGGL((k_tile<T, false>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
   } else {
     hipLaunchKernelGGL((k_tile<T, false>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
   }
@@ -1056,7 +1228,7 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
     TileGate hd;
     std::memset(&hd, 0, sizeof hd);
     hd.kind = TG_GROUP; hd.j0 = (uint8_t)S[0]; hd.j1 = (uint8_t)S[1]; hd.reg_mask = (uint8_t)S[2];
-    hd.count = (uint16_t)entries;
+    hd.count = (uint8_t)entries;
     a->g[a->ngates++] = hd;
     for (size_t mi : grp) {
       const FusedOp& o = ops[members[mi]];
@@ -1078,6 +1250,24 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
       } else {
         g.j0 = (uint8_t)reg_pos(tile_pos(o.target[0]));
         if (o.control >= 0) require_one(o.control);
+      }
+      {   // opcode for k_tile_op
+        int ctrl_reg = -1;
+        for (int r = 0; r < kGroupBits; ++r) if (g.reg_mask & (1u << r)) ctrl_reg = r;
+        auto is = [&](int e, double re, double im) { return o.m[e].x == re && o.m[e].y == im; };
+        if (o.kind == TG_PHASE) {
+          const bool sp = tuning().tile_special;
+          const int fam = !sp ? OPC_PHASE : (is(0, -1, 0) ? OPC_PHASE_NEG : (is(0, 0, 1) ? OPC_PHASE_I : (is(0, 0, -1) ? OPC_PHASE_NI : OPC_PHASE)));
+          g.opcode = (uint8_t)(fam + g.reg_mask);
+        } else if (o.kind == TG_DENSE2) {
+          g.opcode = (uint8_t)(OPC_DENSE2 + 3 * g.j0 + g.j1);
+        } else {
+          int fam = o.kind == TG_DENSE1 ? OPC_DENSE1 : (o.kind == TG_SWAP1 ? OPC_SWAP1 : OPC_ANTI1);
+          const bool sp = tuning().tile_special;
+          if (sp && o.kind == TG_DENSE1 && o.m[0].y == 0 && o.m[1].y == 0 && o.m[2].y == 0 && o.m[3].y == 0) fam = OPC_REAL1;
+          if (sp && o.kind == TG_ANTI1 && is(1, 0, -1) && is(2, 0, 1)) fam = OPC_YLIKE1;
+          g.opcode = (uint8_t)(fam + opc_1q_variant(g.j0, ctrl_reg));
+        }
       }
       const int q = a->ngates;
       for (int e = 0; e < o.nm; ++e) a->mat[4 * q + e] = o.m[e];
