@@ -150,6 +150,8 @@ def main():
     for _ in range(args.warmup):
         engine.execute(plan)
     engine.barrier()
+    if hasattr(engine, "reset_comm_stats"):
+        engine.reset_comm_stats()
     engine.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -167,6 +167,7 @@ class DistributedEngine:
         self.l2p = list(range(n_qubits))      # logical qubit -> physical index bit
         self.xgmi_bytes_sent = 0
         self.exchanges = 0
+        self._comm_events: list = []
 
     # ---- helpers -----------------------------------------------------------------------
     def _rank_bit(self, phys_qubit: int) -> int:
@@ -180,6 +181,10 @@ class DistributedEngine:
         dist, torch = self.dist, self.torch
         if not transfers:
             return
+        timed = transfers[0][1].is_cuda and dist.get_backend() == "nccl"
+        if timed:   # device-side time of the exchange (stream events, summed in comm_stats)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         staged = []
         ops = []
         host = dist.get_backend() == "gloo"
@@ -195,6 +200,9 @@ class DistributedEngine:
             work.wait()
         for dev_t, host_t in staged:
             dev_t.copy_(host_t)
+        if timed:
+            ev1.record()
+            self._comm_events.append((ev0, ev1))
         self.exchanges += 1
 
     # ---- state ---------------------------------------------------------------------------
@@ -414,7 +422,15 @@ class DistributedEngine:
         return self.backend.profile_end() if hasattr(self.backend, "profile_end") else []
 
     def comm_stats(self) -> dict:
-        return {"bytes_sent_per_rank": self.xgmi_bytes_sent, "exchanges": self.exchanges}
+        ms = None
+        if self._comm_events:
+            self.backend.sync()
+            ms = float(sum(a.elapsed_time(b) for a, b in self._comm_events))
+        return {"bytes_sent_per_rank": self.xgmi_bytes_sent, "exchanges": self.exchanges,
+                "exchange_ms_rank0": ms}
+
+    def reset_comm_stats(self) -> None:
+        self.xgmi_bytes_sent, self.exchanges, self._comm_events = 0, 0, []
 
     def close(self) -> None:
         self.backend.close()
