@@ -155,10 +155,14 @@ class DistributedEngine:
         if self.k < 0:
             raise ValueError("more ranks than amplitudes")
         self.mode, self.staging, self.staging_method = mode, staging, staging_method
+        import os
+        rehearsal = backend is None and os.environ.get("QSIM_DIST_BACKEND") == "gloo"
         if backend is None:
+            if rehearsal:   # several ranks share the visible GPU(s); exchange is host-staged over gloo
+                local_rank = local_rank % max(1, torch.cuda.device_count())
             torch.cuda.set_device(local_rank)     # before RCCL initialises: one rank <-> one GPU
         if init_process_group and not dist.is_initialized():
-            if backend is None:
+            if backend is None and not rehearsal:
                 dist.init_process_group("nccl", rank=rank, world_size=world,
                                         device_id=torch.device(f"cuda:{local_rank}"))
             else:
