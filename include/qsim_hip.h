@@ -112,6 +112,11 @@ int qsim_norm2(qsim_chunk* c, double* out);               /* sum |amp|^2        
  *         last), kind 1: GHZ+QFT  2^-(n+1)/2 (1 + exp(-2 pi i y / 2^n)), y = base + i.  */
 int qsim_max_abs_err_closed_form(qsim_chunk* c, int kind, int n_total_qubits,
                                  uint64_t base_index, double* out);
+/* Same for a staged layout: logical qubit q sits at physical index bit log_to_phys[q]
+ * (atlas_stages' second return value, staging.py:587-634); NULL = identity.             */
+int qsim_max_abs_err_closed_form_perm(qsim_chunk* c, int kind, int n_total_qubits,
+                                      uint64_t base_index, const int32_t* log_to_phys,
+                                      double* out);
 int qsim_time_begin(qsim_chunk* c);                        /* hipEventRecord on stream  */
 int qsim_time_end(qsim_chunk* c, float* elapsed_ms);       /* record + synchronize      */
 

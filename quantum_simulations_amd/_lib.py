@@ -64,6 +64,8 @@ SIGNATURES = {
     "qsim_norm2": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "qsim_max_abs_err_closed_form": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64,
                                                C.POINTER(C.c_double)]),
+    "qsim_max_abs_err_closed_form_perm": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64, _P,
+                                                    C.POINTER(C.c_double)]),
     "qsim_time_begin": (C.c_int, [_P]),
     "qsim_time_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "qsim_profile_begin": (C.c_int, [_P]),

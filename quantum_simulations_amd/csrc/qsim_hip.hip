@@ -1485,15 +1485,23 @@ __global__ __launch_bounds__(kBlock) void k_norm2_partial(const double2* p, u64 
 }
 
 // kind 0: GHZ, kind 1: GHZ+QFT closed form.  `base` = global index of amp 0.
+struct BitPerm { unsigned char to_logical[64]; int active; };   // physical index bit -> logical qubit
+
 __global__ __launch_bounds__(kBlock) void k_closed_form_err(const double2* p, u64 n, int kind,
-                                                            int n_total, u64 base, double* partial) {
+                                                            int n_total, u64 base, double* partial,
+                                                            const BitPerm perm) {
   const u64 stride = (u64)gridDim.x * blockDim.x;
   const double inv_n = exp2(-(double)n_total);
   const double amp = exp2(-0.5 * (double)(n_total + 1));
   const u64 last = (n_total >= 64) ? ~0ull : ((1ull << n_total) - 1);
   double worst = 0.0;
   for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const u64 y = base + i;
+    u64 y = base + i;
+    if (perm.active) {                       // staged layout: logical index from the physical one
+      const u64 x = y;
+      y = 0;
+      for (int b = 0; b < n_total; ++b) y |= ((x >> b) & 1ull) << perm.to_logical[b];
+    }
     double er, ei;
     if (kind == 0) {
       er = (y == 0 || y == last) ? 0.70710678118654752440 : 0.0;
@@ -1881,16 +1889,37 @@ int qsim_sync(qsim_chunk* c) {
   return QSIM_OK;
 }
 
+int qsim_max_abs_err_closed_form_perm(qsim_chunk* c, int kind, int n_total_qubits, uint64_t base_index,
+                                      const int32_t* log_to_phys, double* out);
+
 int qsim_max_abs_err_closed_form(qsim_chunk* c, int kind, int n_total_qubits, uint64_t base_index, double* out) {
+  return qsim_max_abs_err_closed_form_perm(c, kind, n_total_qubits, base_index, nullptr, out);
+}
+
+int qsim_max_abs_err_closed_form_perm(qsim_chunk* c, int kind, int n_total_qubits, uint64_t base_index,
+                                      const int32_t* log_to_phys, double* out) {
   int rc = check_chunk(c, "qsim_max_abs_err_closed_form");
   if (rc) return rc;
   if (!out || (kind != 0 && kind != 1) || n_total_qubits < c->k || n_total_qubits > 52)
     return fail(QSIM_ERR_INVALID, "qsim_max_abs_err_closed_form: bad arguments");
+  BitPerm perm;
+  std::memset(&perm, 0, sizeof perm);
+  if (log_to_phys) {
+    u64 seen = 0;
+    for (int q = 0; q < n_total_qubits; ++q) {
+      const int ph = log_to_phys[q];
+      if (ph < 0 || ph >= n_total_qubits || (seen >> ph) & 1)
+        return fail(QSIM_ERR_INVALID, "qsim_max_abs_err_closed_form: log_to_phys is not a permutation");
+      seen |= 1ull << ph;
+      perm.to_logical[ph] = (unsigned char)q;
+      if (ph != q) perm.active = 1;
+    }
+  }
   if ((rc = ensure_scratch(c))) return rc;
   HIP_TRY(hipSetDevice(c->device));
   const unsigned grid = std::min<unsigned>(stream_grid(amps(c)), kReduceBlocks);
   hipLaunchKernelGGL(k_closed_form_err, dim3(grid), dim3(kBlock), 0, c->stream, c->amp, amps(c), kind,
-                     n_total_qubits, (u64)base_index, c->scratch);
+                     n_total_qubits, (u64)base_index, c->scratch, perm);
   HIP_TRY(hipGetLastError());
   std::vector<double> host(grid);
   HIP_TRY(hipMemcpyAsync(host.data(), c->scratch, sizeof(double) * grid, hipMemcpyDeviceToHost, c->stream));

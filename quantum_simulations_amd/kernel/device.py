@@ -149,11 +149,15 @@ class DeviceChunk:
         _lib.check(_lib.load().qsim_norm2(self._h, C.byref(out)))
         return out.value
 
-    def max_abs_err_closed_form(self, kind: str, n_total: int, base_index: int = 0) -> float:
+    def max_abs_err_closed_form(self, kind: str, n_total: int, base_index: int = 0,
+                                log_to_phys=None) -> float:
+        """max |amp - closed form| over this chunk; `log_to_phys` maps a staged layout back."""
         out = C.c_double()
         code = {"ghz": 0, "ghz_qft": 1}[kind]
-        _lib.check(_lib.load().qsim_max_abs_err_closed_form(self._h, code, n_total, base_index,
-                                                            C.byref(out)))
+        perm = None if log_to_phys is None else np.asarray(log_to_phys, dtype=np.int32)
+        _lib.check(_lib.load().qsim_max_abs_err_closed_form_perm(
+            self._h, code, n_total, base_index,
+            None if perm is None else perm.ctypes.data_as(C.c_void_p), C.byref(out)))
         return out.value
 
     def time_begin(self) -> None:

@@ -119,6 +119,9 @@ class HipShardBackend:
     def unpack_bits(self, bits, pattern: int, src: str, src_offset: int) -> None:
         self.chunk("state").unpack_bits(bits, pattern, self.chunk(src), src_offset)
 
+    def closed_form_error(self, kind: str, n_total: int, base_index: int, log_to_phys) -> float:
+        return self.chunk("state").max_abs_err_closed_form(kind, n_total, base_index, log_to_phys)
+
     def profile_begin(self) -> None:
         self.chunk("state").profile_begin()
 
@@ -424,6 +427,12 @@ class DistributedEngine:
 
     def profile_end(self):
         return self.backend.profile_end() if hasattr(self.backend, "profile_end") else []
+
+    def closed_form_error(self, kind: str) -> float:
+        """max over ALL 2^n amplitudes of |amp - closed form| ("ghz" / "ghz_qft"),
+        evaluated on every shard in its current (staged) layout and max-reduced over ranks."""
+        local = self.backend.closed_form_error(kind, self.n, self.rank << self.k, self.l2p)
+        return self.max_over_ranks(local)
 
     def comm_stats(self) -> dict:
         ms = None

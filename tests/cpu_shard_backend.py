@@ -68,5 +68,16 @@ class CpuShardBackend:
         sel = self._slab_index(bits, pattern)
         self._c("state")[sel] = self._c(src)[src_offset:src_offset + sel.size]
 
+    def closed_form_error(self, kind, n_total, base_index, log_to_phys) -> float:
+        x = base_index + np.arange(1 << self.k, dtype=np.int64)
+        y = np.zeros_like(x)
+        for q, p in enumerate(log_to_phys):
+            y |= ((x >> p) & 1) << q
+        if kind == "ghz":
+            want = np.where((y == 0) | (y == (1 << n_total) - 1), 2 ** -0.5, 0.0).astype(np.complex128)
+        else:
+            want = orc.ghz_qft_closed_form(n_total, y)
+        return float(np.max(np.abs(self._c("state") - want)))
+
     def close(self) -> None:
         self._t.clear()

@@ -71,6 +71,8 @@ def _worker(rank, world, port, n, staging_modes, errors):
                 got = eng.state_vector()
                 err = float(np.max(np.abs(got - want)))
                 assert err < 1e-12, f"{name} staging={staging}/{method} world={world}: {err}"
+                if name in ("ghz", "ghz_qft"):   # closed form evaluated shard by shard in the staged layout
+                    assert eng.closed_form_error(name) < 1e-12
                 assert abs(eng.norm2() - 1.0) < 1e-12
                 # second execution continues from the permuted layout: psi2 = C(C|0>)
                 eng.execute(plan)

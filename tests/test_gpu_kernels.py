@@ -371,3 +371,40 @@ def test_ghz_33q_single_gpu_64bit_indexing(hip):
     tail = dev.download((1 << n) - 2, 2)
     assert abs(tail[1] - 2 ** -0.5) < 1e-12 and tail[0] == 0
     dev.close()
+
+
+def test_config3_sweep_is_unitary_30q(hip):
+    """BASELINE config 3 at full size: H on every target 0..29 of a 30-qubit random state, twice
+    (H.H = I): the state must come back to 1e-12 and the norm must hold after every gate."""
+    n = 30
+    dev = hip.DeviceChunk.empty(n)
+    dev.init_random(30)
+    probes = [(0, 4096), ((1 << 29) - 2048, 4096), ((1 << n) - 4096, 4096)]
+    before = [dev.download(o, c) for o, c in probes]
+    H = orc.gate_matrix("H")
+    for q in range(n):
+        dev.apply_1q(q, H)
+        if q % 7 == 0:
+            assert abs(dev.norm2() - 1.0) < 1e-12
+        dev.apply_1q(q, H)
+    for (o, c), want in zip(probes, before):
+        np.testing.assert_allclose(dev.download(o, c), want, rtol=0, atol=1e-12)
+    dev.close()
+
+
+def test_closed_form_checker_with_staged_layout(hip):
+    """The on-device closed-form checker undoes a staging permutation: permute GHZ+QFT amplitudes
+    on the host, upload, check with log_to_phys."""
+    from quantum_simulations_amd.circuits import generate_ghz_qft
+    n = 12
+    psi = orc.simulate(generate_ghz_qft(n))
+    l2p = list(np.random.default_rng(5).permutation(n))
+    x = np.arange(1 << n)
+    y = np.zeros_like(x)
+    for q, p in enumerate(l2p):
+        y |= ((x >> p) & 1) << q
+    phys = psi[y]                      # physical index x holds logical amplitude y(x)
+    dev = hip.DeviceChunk.from_numpy(phys)
+    assert dev.max_abs_err_closed_form("ghz_qft", n, 0, [int(p) for p in l2p]) < 1e-12
+    assert dev.max_abs_err_closed_form("ghz_qft", n, 0) > 1e-3      # wrong without the mapping
+    dev.close()
