@@ -315,28 +315,16 @@ struct Tuning {
   int swz_cut = 64;   // XCD-contiguous block order when the highest removed bit is below this (r01 scan: always)
   int force_nt = -1;  // -1 auto, 0 never, 1 always
   int items = 0;      // 0 auto
-  int tile_bits = 11; // LDS tile = 2^tile_bits amplitudes (8..12); r01 scan: 11 beats 12 and 10
-  int max_gates_per_pass = 48;
-  int tile_wgs_per_cu = 8;   // upper bound; the occupancy query decides
-  int num_cus = 256;
+  int max_gates_per_pass = 128;
+  int tile_special = 1;      // real / Y-like / -1 / +-i special-case opcodes in fused passes
   int debug_skip_gates = 0;  // QSIM_DEBUG_SKIP_GATES=1: tile passes move data but apply nothing (WRONG results)
-  int tile_special = 1;      // real / Y-like / -1 / +-i special-case opcodes
-  int tile_opcode = 1;       // opcode-dispatched gate loop (k_tile_op) where one block per thread fits
-  int tile_persistent = 0;   // r01: one-shot grid (5 WGs/CU) beats the persistent prefetching form (3 WGs/CU)
   Tuning() {
-    if (const char* e = getenv("QSIM_TILE_PERSIST")) tile_persistent = atoi(e);
-    if (const char* e = getenv("QSIM_TILE_OPCODE")) tile_opcode = atoi(e);
-    if (const char* e = getenv("QSIM_TILE_SPECIAL")) tile_special = atoi(e);
-    if (const char* e = getenv("QSIM_DEBUG_SKIP_GATES")) debug_skip_gates = atoi(e);
-    if (const char* e = getenv("QSIM_TILE_WGS")) tile_wgs_per_cu = std::max(1, atoi(e));
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, 0) == hipSuccess && prop.multiProcessorCount > 0)
-      num_cus = prop.multiProcessorCount;
-    if (const char* e = getenv("QSIM_TILE_BITS")) tile_bits = std::min(12, std::max(8, atoi(e)));
-    if (const char* e = getenv("QSIM_PASS_GATES")) max_gates_per_pass = std::max(1, atoi(e));
     if (const char* e = getenv("QSIM_SWZ_CUT")) swz_cut = atoi(e);
     if (const char* e = getenv("QSIM_NT")) force_nt = atoi(e);
     if (const char* e = getenv("QSIM_ITEMS")) items = atoi(e);
+    if (const char* e = getenv("QSIM_PASS_GATES")) max_gates_per_pass = std::max(1, atoi(e));
+    if (const char* e = getenv("QSIM_TILE_SPECIAL")) tile_special = atoi(e);
+    if (const char* e = getenv("QSIM_DEBUG_SKIP_GATES")) debug_skip_gates = atoi(e);
   }
 };
 static const Tuning& tuning() {
@@ -625,50 +613,64 @@ static int gate_2q(const Group& g, int qa, int qb, const double* U, hipStream_t 
 // wenbo_engine/circuit/fusion.py:86-142, and of v3's fused independent-gate block,
 // parallel_gate_applicator.py:169-204): a workgroup loads a *tile* of 2^T amplitudes into LDS,
 // applies every gate of the pass whose target bits are tile bits, and stores the tile back.
-//   tile bits = the kTileLow lowest index bits (so every global access is a run of
-//   2^kTileLow amplitudes = 256 B, whole lines, NT) + up to T - kTileLow arbitrary higher bits.
+//   tile bits = the kTileLow lowest index bits (every global access is a whole 128-B line, NT)
+//   + T - kTileLow arbitrary higher bits chosen by the gates of the pass.
 //   Control bits and diagonal bits may lie OUTSIDE the tile: they become a per-tile predicate.
 // Inside the tile gates are applied in *register groups*: a group owns kGroupBits tile bits;
-// each thread pulls the 2^kGroupBits amplitudes that differ in those bits from LDS, applies
-// every gate of the group in registers, and writes them back once -- LDS traffic is paid per
-// group, not per gate (measured: the per-gate LDS loop was LDS-write bound, 79 B/clk/CU).
-// LDS slots are XOR-swizzled (slot = t ^ ((t >> 4) & 15)) so both the global-side row accesses
-// and the register-group accesses on low tile bits are bank-conflict free.
+// each thread pulls the 2^kGroupBits amplitudes that differ in those bits from LDS into eight
+// NAMED registers, applies every gate of the group on them, and writes them back once -- LDS
+// traffic is paid per group, not per gate.
+// The gate loop is instruction-issue bound (rocprofv3: SALU ~ VALU, one scalar unit per CU), so
+// the host pre-decodes every gate into ONE opcode byte selecting a straight-line case (every
+// kind x register target x register control combination, plus special cases for real matrices,
+// Y-like gates and -1 / +-i phases) and ready-made predicate masks.
 // Algorithmic bytes per pass: 32 B x 2^k (every amplitude read and written once), for g gates.
 #ifndef QSIM_TILE_LOW
 #define QSIM_TILE_LOW 3
 #endif
 constexpr int kTileLow = QSIM_TILE_LOW;
+constexpr int kTileBitsMax = 11;       // 2^11 amplitudes = 32 KiB of LDS: 4-5 workgroups per CU
 constexpr int kGroupBits = 3;
 constexpr int kGroupAmps = 1 << kGroupBits;
-constexpr int kTileMaxGates = 48;      // gate entries incl. group headers and padding
-constexpr int kTileMaxMat = 4 * kTileMaxGates;   // gate entry q owns mat[4q .. 4q+3] (fixed stride)
+constexpr int kTileThreads = 256;
+constexpr int kTileThreadBits = 8;
+constexpr int kTileMaxGates = 144;     // entries incl. group headers  (2304 B of kernel arguments)
+constexpr int kTileMaxMat = 104;       // complex matrix pool          (1664 B)
 
 enum : uint8_t {
-  TG_DENSE1 = 0,   // 2x2 on register bit j0
-  TG_PHASE = 1,    // multiply selected amplitudes by mat[0]
-  TG_DENSE2 = 2,   // 4x4 on register bits (j0 = qa, j1 = qb)
-  TG_ANTI1 = 3,    // 2x2 with zero diagonal: a' = u01 b, b' = u10 a   (Y, CY)
-  TG_SWAP1 = 4,    // a <-> b                                        (X, CNOT)
-  TG_NOP = 5,      // padding: the three entries after a 4x4 gate hold the rest of its matrix
-  TG_GROUP = 0xFE  // header: j0, j1, reg_mask hold the group's three tile bits (ascending)
+  OPC_NOP = 0,
+  OPC_DENSE1 = 1,     // +variant 0..8: general 2x2                           (pool: 4)
+  OPC_SWAP1 = 10,     // +variant: a <-> b                  X, CNOT           (pool: 0)
+  OPC_ANTI1 = 19,     // +variant: a' = u01 b, b' = u10 a                     (pool: 4)
+  OPC_PHASE = 28,     // +register mask 0..7: x *= m[0]     T, R, CR          (pool: 1)
+  OPC_DENSE2 = 36,    // +3*JA + JB: general 4x4, SWAP                        (pool: 16)
+  OPC_REAL1 = 45,     // +variant: 2x2 with real entries    H, RY, G          (pool: 4)
+  OPC_YLIKE1 = 54,    // +variant: [[0,-i],[i,0]]           Y, CY             (pool: 0)
+  OPC_PHASE_NEG = 63, // +mask: x = -x                      Z, CZ             (pool: 0)
+  OPC_PHASE_I = 71,   // +mask: x = i x                     S                 (pool: 0)
+  OPC_PHASE_NI = 79,  // +mask: x = -i x                                      (pool: 0)
+  OPC_GROUP = 0xFE    // group header
 };
+// 1q variant: 0..2 = target register bit J, no register control; 3 + 2*J + k = control on the
+// k-th of the two other register bits (ascending)
+static inline int opc_1q_variant(int J, int C) {
+  return C < 0 ? J : 3 + 2 * J + ((C > J ? C - 1 : C) == 0 ? 0 : 1);
+}
 
-struct alignas(16) TileGate {   // 16 bytes: one s_load_dwordx4; predicates are ready-made masks
-  uint8_t kind;
-  uint8_t j0, j1;          // register bit indices (0 .. kGroupBits-1); group header: s0, s1
-  uint8_t reg_mask;        // register bits that must be 1 (controls / phase bits inside the group);
-                           // group header: s2
-  uint16_t blk_mask;       // tile bits outside the group that must be 1
-  uint8_t count;           // group header: entries in the group (gates + padding)
-  uint8_t opcode;          // pre-decoded (kind, register target, register control) for k_tile_op
+struct alignas(16) TileGate {   // 16 bytes: one s_load_dwordx4
+  uint8_t opcode;
+  uint8_t count;           // group header: entries in the group
+  uint16_t blk_mask;       // gate: tile bits OUTSIDE the group that must be 1;
+                           // group header: s0 | s1 << 4 | s2 << 8 (ascending tile bits)
+  uint16_t mat;            // gate: first TileArgs::mat entry of its matrix (0 when it has none)
+  uint16_t pad;
   uint64_t outer_mask;     // absolute index bits outside the tile that must be 1
 };
 
 struct TileArgs {
   double2* amp;
-  int nh;                  // tile high bits
   int ngates;
+  int pad;
   uint8_t h[16];           // ascending absolute positions of the tile's high bits
   TileGate g[kTileMaxGates];
   double2 mat[kTileMaxMat];
@@ -678,255 +680,22 @@ static_assert(sizeof(TileArgs) <= 4096, "kernel arguments must fit 4 KiB");
 __device__ __forceinline__ unsigned insert_zero(unsigned c, int p) {
   return ((c >> p) << (p + 1)) | (c & ((1u << p) - 1));
 }
+// XOR-swizzled LDS slot (measured: within 1 % of five other swizzles and of none -- bank
+// conflicts are not what limits the gate phase)
 __device__ __forceinline__ unsigned lds_slot(unsigned t) { return t ^ ((t >> 4) & 15u); }
-
-template <int J>
-__device__ __forceinline__ void reg_dense1(double2 (&x)[kGroupAmps], const double2* m, unsigned rm) {
-  const double2 u00 = m[0], u01 = m[1], u10 = m[2], u11 = m[3];
-#pragma unroll
-  for (int i = 0; i < kGroupAmps; ++i) {
-    if ((i >> J) & 1) continue;
-    if ((i & rm) != rm) continue;
-    const double2 a = x[i], b = x[i | (1 << J)];
-    x[i] = cfma(u01, b, cmul(u00, a));
-    x[i | (1 << J)] = cfma(u11, b, cmul(u10, a));
-  }
-}
-template <int J>
-__device__ __forceinline__ void reg_anti1(double2 (&x)[kGroupAmps], const double2* m, unsigned rm) {
-  const double2 u01 = m[1], u10 = m[2];
-#pragma unroll
-  for (int i = 0; i < kGroupAmps; ++i) {
-    if ((i >> J) & 1) continue;
-    if ((i & rm) != rm) continue;
-    const double2 a = x[i], b = x[i | (1 << J)];
-    x[i] = cmul(u01, b);
-    x[i | (1 << J)] = cmul(u10, a);
-  }
-}
-template <int J>
-__device__ __forceinline__ void reg_swap1(double2 (&x)[kGroupAmps], unsigned rm) {
-#pragma unroll
-  for (int i = 0; i < kGroupAmps; ++i) {
-    if ((i >> J) & 1) continue;
-    if ((i & rm) != rm) continue;
-    const double2 a = x[i];
-    x[i] = x[i | (1 << J)];
-    x[i | (1 << J)] = a;
-  }
-}
-template <int JA, int JB>
-__device__ __forceinline__ void reg_dense2(double2 (&x)[kGroupAmps], const double2* m) {
-#pragma unroll
-  for (int i = 0; i < kGroupAmps; ++i) {
-    if (((i >> JA) & 1) || ((i >> JB) & 1)) continue;
-    const double2 v0 = x[i], v1 = x[i | (1 << JB)], v2 = x[i | (1 << JA)], v3 = x[i | (1 << JA) | (1 << JB)];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double2 acc = cmul(m[4 * r], v0);
-      acc = cfma(m[4 * r + 1], v1, acc);
-      acc = cfma(m[4 * r + 2], v2, acc);
-      acc = cfma(m[4 * r + 3], v3, acc);
-      x[i | ((r & 2) ? (1 << JA) : 0) | ((r & 1) ? (1 << JB) : 0)] = acc;
-    }
-  }
-}
-
-// The gate loop is bound by the CU's single scalar unit (descriptor decode + uniform branches
-// are paid per wave per gate), so a tile is worked by FEW waves with MORE register blocks each:
-// kTileThreads = 128 (2 waves, 2 blocks of 8 amplitudes per thread at T = 11) measured faster
-// than 256 threads (4 waves, 1 block).
-#ifndef QSIM_TILE_THREADS
-#define QSIM_TILE_THREADS 256
-#endif
-constexpr int kTileThreads = QSIM_TILE_THREADS;
-constexpr int kTileThreadBits = kTileThreads == 64 ? 6 : (kTileThreads == 128 ? 7 : (kTileThreads == 256 ? 8 : (kTileThreads == 512 ? 9 : 10)));
-
-// min waves per SIMD asked of the register allocator: what the LDS footprint admits, capped at 4
-// (5 forces spills at T = 11 and measured slower)
-constexpr int tile_waves(int T) {
-  return (160 * 1024) / ((1 << T) * 16) * (kTileThreads / 64) / 4 > 4 ? 4
-         : ((160 * 1024) / ((1 << T) * 16) * (kTileThreads / 64) / 4 < 1 ? 1 : (160 * 1024) / ((1 << T) * 16) * (kTileThreads / 64) / 4);
-}
-
-template <int T, bool PERSIST>
-__global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const TileArgs a, const unsigned ntiles) {
-  constexpr int N = 1 << T;
-  constexpr int LOW = kTileLow;
-  constexpr int NH = T - LOW;                         // tile high bits (host guarantees a.nh == NH)
-  constexpr int BLOCK = kTileThreads;
-  constexpr int TB = kTileThreadBits;                 // thread id bits: LOW element bits + row bits
-  constexpr int PER = N / BLOCK > 0 ? N / BLOCK : 1;  // tile elements per thread
-  const bool elem_ok = N >= BLOCK || (int)threadIdx.x < N;   // tiny tiles: surplus threads idle
-  constexpr int NBLK = N >> kGroupBits;               // register blocks per tile
-  constexpr int NB = (NBLK + BLOCK - 1) / BLOCK;      // register blocks per thread
-  __shared__ double2 lds[N];
-  const int tid = threadIdx.x;
-  // global index of a tile's element 0: the tile number enumerates the non-tile bits
-  auto tile_base = [&](unsigned tile) -> u64 {
-    u64 base = (u64)tile << LOW;
-#pragma unroll
-    for (int j = 0; j < NH; ++j) {
-      const int p = a.h[j];
-      base = ((base >> p) << (p + 1)) | (base & ((1ull << p) - 1));
-    }
-    return base;
-  };
-  // element t = tid + BLOCK * j -> row = (tid >> LOW) | (j << (TB - LOW)): the thread part of the
-  // offset is computed once, the j part is wave-uniform (scalar registers)
-  u64 off_tid = tid & ((1 << LOW) - 1);
-#pragma unroll
-  for (int i = 0; i < TB - LOW && i < NH; ++i) off_tid |= (u64)((tid >> (LOW + i)) & 1) << a.h[i];   // tid < N
-  auto off_j = [&](int j) -> u64 {
-    u64 o = 0;
-#pragma unroll
-    for (int i = TB - LOW; i < NH; ++i) o |= (u64)((j >> (i - (TB - LOW))) & 1) << a.h[i];
-    return o;
-  };
-  unsigned tile = blockIdx.x;
-  u64 base = tile_base(tile);
-  double2 v[PER];
-#pragma unroll
-  for (int j = 0; j < PER; ++j) if (elem_ok) v[j] = ld_amp<true>(a.amp + base + off_tid + off_j(j));
-  for (;;) {
-#pragma unroll
-  for (int j = 0; j < PER; ++j) if (elem_ok) lds[lds_slot(tid + BLOCK * j)] = v[j];
-  __syncthreads();
-  const unsigned next = tile + gridDim.x;
-  const bool has_next = PERSIST && next < ntiles;
-  u64 next_base = 0;
-  if (PERSIST && has_next) {
-    next_base = tile_base(next);
-#pragma unroll
-    for (int j = 0; j < PER; ++j) if (elem_ok) v[j] = ld_amp<true>(a.amp + next_base + off_tid + off_j(j));
-  }
-
-  int gi = 0;
-  while (gi < a.ngates) {
-    gi = __builtin_amdgcn_readfirstlane(gi);          // keep the descriptor reads scalar
-    const TileGate hd = a.g[gi++];                    // group header
-    const int s0 = hd.j0, s1 = hd.j1, s2 = hd.reg_mask;   // ascending tile bits
-    const int ge = gi + hd.count;
-    double2 x[NB][kGroupAmps];
-    unsigned tb[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const unsigned blk = tid + b * BLOCK;
-      tb[b] = insert_zero(insert_zero(insert_zero(blk, s0), s1), s2);
-      if (NBLK % BLOCK == 0 || blk < NBLK) {
-#pragma unroll
-        for (int i = 0; i < kGroupAmps; ++i) {
-          const unsigned t = tb[b] | ((i & 1) << s0) | (((i >> 1) & 1) << s1) | (((i >> 2) & 1) << s2);
-          x[b][i] = lds[lds_slot(t)];
-        }
-      }
-    }
-    for (int q0 = gi; q0 < ge; ++q0) {
-      const int q = __builtin_amdgcn_readfirstlane(q0);
-      const TileGate g = a.g[q];
-      const double2* m = a.mat + 4 * q;               // fixed stride: load independent of g
-      if ((base & g.outer_mask) != g.outer_mask) continue;
-      const unsigned rm = g.reg_mask;
-      const unsigned bm = g.blk_mask;
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        if ((tb[b] & bm) != bm) continue;
-        switch (g.kind) {
-          case TG_DENSE1:
-            if (g.j0 == 0) reg_dense1<0>(x[b], m, rm); else if (g.j0 == 1) reg_dense1<1>(x[b], m, rm); else reg_dense1<2>(x[b], m, rm);
-            break;
-          case TG_ANTI1:
-            if (g.j0 == 0) reg_anti1<0>(x[b], m, rm); else if (g.j0 == 1) reg_anti1<1>(x[b], m, rm); else reg_anti1<2>(x[b], m, rm);
-            break;
-          case TG_SWAP1:
-            if (g.j0 == 0) reg_swap1<0>(x[b], rm); else if (g.j0 == 1) reg_swap1<1>(x[b], rm); else reg_swap1<2>(x[b], rm);
-            break;
-          case TG_PHASE: {
-            const double2 d = m[0];
-#pragma unroll
-            for (int i = 0; i < kGroupAmps; ++i)
-              if ((i & rm) == rm) x[b][i] = cmul(d, x[b][i]);
-            break;
-          }
-          case TG_NOP:
-            break;
-          default: {
-            const int key = g.j0 * 3 + g.j1;
-            if (key == 1) reg_dense2<0, 1>(x[b], m); else if (key == 2) reg_dense2<0, 2>(x[b], m);
-            else if (key == 3) reg_dense2<1, 0>(x[b], m); else if (key == 5) reg_dense2<1, 2>(x[b], m);
-            else if (key == 6) reg_dense2<2, 0>(x[b], m); else reg_dense2<2, 1>(x[b], m);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (NBLK % BLOCK == 0 || tid + b * BLOCK < NBLK) {
-#pragma unroll
-        for (int i = 0; i < kGroupAmps; ++i) {
-          const unsigned t = tb[b] | ((i & 1) << s0) | (((i >> 1) & 1) << s1) | (((i >> 2) & 1) << s2);
-          lds[lds_slot(t)] = x[b][i];
-        }
-      }
-    }
-    __syncthreads();
-    gi = ge;
-  }
-  {
-    double2 w[PER];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) if (elem_ok) w[j] = lds[lds_slot(tid + BLOCK * j)];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) if (elem_ok) st_amp<true>(a.amp + base + off_tid + off_j(j), w[j]);
-  }
-  if (!PERSIST || !has_next) break;
-  tile = next;
-  base = next_base;
-  }  // persistent tile loop (each thread re-writes only the LDS slots it just read: no barrier)
-}
-
-// ---- k_tile_op: the same tile pass with an opcode-dispatched gate loop --------------------------
-// One register block (8 named amplitudes x0..x7) per thread; every (kind, register target,
-// register control) combination is its own straight-line case selected by ONE opcode byte the
-// host computed, so a gate costs a descriptor load, two mask tests, one switch and the math --
-// no per-pair control tests, no bit-field decoding (the generic k_tile loop spends ~75 scalar
-// instructions per gate and wave on those; the CU has a single scalar unit).
-enum : uint8_t {
-  OPC_NOP = 0,
-  OPC_DENSE1 = 1,     // +0..8: variants below
-  OPC_SWAP1 = 10,     // +0..8
-  OPC_ANTI1 = 19,     // +0..8
-  OPC_PHASE = 28,     // +register mask 0..7
-  OPC_DENSE2 = 36,    // +3*JA + JB
-  OPC_REAL1 = 45,     // +0..8: 2x2 with real entries (H, RY, G, real products): half the multiplies
-  OPC_YLIKE1 = 54,    // +0..8: [[0,-i],[i,0]] (Y, CY): swaps and sign flips only
-  OPC_PHASE_NEG = 63, // +mask: multiply by -1 (Z, CZ)
-  OPC_PHASE_I = 71,   // +mask: multiply by +i (S)
-  OPC_PHASE_NI = 79   // +mask: multiply by -i
-};
-// 1q variant: 0..2 = target bit J without register control; 3 + 2*J + k = control on the k-th of
-// the two other register bits (ascending)
-static inline int opc_1q_variant(int J, int C) {
-  return C < 0 ? J : 3 + 2 * J + ((C > J ? C - 1 : C) == 0 ? 0 : 1);
-}
 
 #define QS_D1(A, B) { const double2 a_ = A, b_ = B; A = cfma(u01, b_, cmul(u00, a_)); B = cfma(u11, b_, cmul(u10, a_)); }
 #define QS_AN(A, B) { const double2 a_ = A, b_ = B; A = cmul(u01, b_); B = cmul(u10, a_); }
 #define QS_SW(A, B) { const double2 t_ = A; A = B; B = t_; }
-#define QS_PH(A) { A = cmul(u00, A); }
 #define QS_DR(A, B) { const double2 a_ = A, b_ = B;                                               \
     A = make_double2(fma(u01.x, b_.x, u00.x * a_.x), fma(u01.x, b_.y, u00.x * a_.y));               \
     B = make_double2(fma(u11.x, b_.x, u10.x * a_.x), fma(u11.x, b_.y, u10.x * a_.y)); }
 #define QS_YL(A, B) { const double2 a_ = A, b_ = B; A = make_double2(b_.y, -b_.x); B = make_double2(-a_.y, a_.x); }
+#define QS_PH(A) { A = cmul(u00, A); }
 #define QS_PN(A) { A = make_double2(-A.x, -A.y); }
 #define QS_PI(A) { A = make_double2(-A.y, A.x); }
 #define QS_PM(A) { A = make_double2(A.y, -A.x); }
-#define QS_CASES_PHASE(BASE, OP)                                                                  \
-  case BASE + 0: OP(x0) OP(x1) OP(x2) OP(x3) OP(x4) OP(x5) OP(x6) OP(x7) break;                   \
-  case BASE + 1: OP(x1) OP(x3) OP(x5) OP(x7) break;  case BASE + 2: OP(x2) OP(x3) OP(x6) OP(x7) break; \
-  case BASE + 3: OP(x3) OP(x7) break;                case BASE + 4: OP(x4) OP(x5) OP(x6) OP(x7) break; \
-  case BASE + 5: OP(x5) OP(x7) break;                case BASE + 6: OP(x6) OP(x7) break;          \
-  case BASE + 7: OP(x7) break;
+// register pairs (bit J clear / set) of each 1q variant
 #define QS_PAIRS_0(OP) OP(x0, x1) OP(x2, x3) OP(x4, x5) OP(x6, x7)
 #define QS_PAIRS_1(OP) OP(x0, x2) OP(x1, x3) OP(x4, x6) OP(x5, x7)
 #define QS_PAIRS_2(OP) OP(x0, x4) OP(x1, x5) OP(x2, x6) OP(x3, x7)
@@ -942,7 +711,13 @@ static inline int opc_1q_variant(int J, int C) {
   case BASE + 4: QS_PAIRS_4(OP) break;  case BASE + 5: QS_PAIRS_5(OP) break;             \
   case BASE + 6: QS_PAIRS_6(OP) break;  case BASE + 7: QS_PAIRS_7(OP) break;             \
   case BASE + 8: QS_PAIRS_8(OP) break;
-// 4x4 on (v00, v01 = qb set, v10 = qa set, v11); matrix rows from the gate's 16 entries
+#define QS_CASES_PHASE(BASE, OP)                                                                  \
+  case BASE + 0: OP(x0) OP(x1) OP(x2) OP(x3) OP(x4) OP(x5) OP(x6) OP(x7) break;                   \
+  case BASE + 1: OP(x1) OP(x3) OP(x5) OP(x7) break;  case BASE + 2: OP(x2) OP(x3) OP(x6) OP(x7) break; \
+  case BASE + 3: OP(x3) OP(x7) break;                case BASE + 4: OP(x4) OP(x5) OP(x6) OP(x7) break; \
+  case BASE + 5: OP(x5) OP(x7) break;                case BASE + 6: OP(x6) OP(x7) break;          \
+  case BASE + 7: OP(x7) break;
+// 4x4 on (v00, v01 = qb set, v10 = qa set, v11); the 16 entries are read where they are used
 #define QS_D2(V0, V1, V2, V3) {                                                                         \
     const double2 a_ = V0, b_ = V1, c_ = V2, d_ = V3;                                                   \
     V0 = cfma(a.mat[mq + 3], d_, cfma(a.mat[mq + 2], c_, cfma(a.mat[mq + 1], b_, cmul(a.mat[mq + 0], a_))));     \
@@ -950,25 +725,34 @@ static inline int opc_1q_variant(int J, int C) {
     V2 = cfma(a.mat[mq + 11], d_, cfma(a.mat[mq + 10], c_, cfma(a.mat[mq + 9], b_, cmul(a.mat[mq + 8], a_))));   \
     V3 = cfma(a.mat[mq + 15], d_, cfma(a.mat[mq + 14], c_, cfma(a.mat[mq + 13], b_, cmul(a.mat[mq + 12], a_)))); }
 
+// min waves per SIMD asked of the register allocator: what the LDS footprint admits, capped at 4
+// (5 forces spills at T = 11 and measured slower)
+constexpr int tile_waves(int T) {
+  return (160 * 1024) / ((1 << T) * 16) > 4 ? 4 : (160 * 1024) / ((1 << T) * 16);
+}
+
 template <int T>
-__global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile_op(const TileArgs a, const unsigned ntiles) {
+__global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const TileArgs a) {
   constexpr int N = 1 << T;
   constexpr int LOW = kTileLow;
-  constexpr int NH = T - LOW;
+  constexpr int NH = T - LOW;                         // tile high bits
   constexpr int BLOCK = kTileThreads;
-  constexpr int TB = kTileThreadBits;
-  constexpr int PER = N / BLOCK > 0 ? N / BLOCK : 1;
-  constexpr int NBLK = N >> kGroupBits;
-  static_assert(NBLK <= BLOCK, "k_tile_op keeps one register block per thread");
+  constexpr int TB = kTileThreadBits;                 // thread id bits: LOW element bits + row bits
+  constexpr int PER = N / BLOCK > 0 ? N / BLOCK : 1;  // tile elements per thread
+  constexpr int NBLK = N >> kGroupBits;               // register blocks per tile (<= BLOCK)
+  static_assert(NBLK <= BLOCK, "one register block per thread");
   __shared__ double2 lds[N];
   const int tid = threadIdx.x;
-  const bool elem_ok = N >= BLOCK || tid < N;
+  const bool elem_ok = N >= BLOCK || tid < N;         // tiny tiles: surplus threads idle
+  // global index of the tile's element 0: blockIdx enumerates the non-tile bits
   u64 base = (u64)blockIdx.x << LOW;
 #pragma unroll
   for (int j = 0; j < NH; ++j) {
     const int p = a.h[j];
     base = ((base >> p) << (p + 1)) | (base & ((1ull << p) - 1));
   }
+  // element t = tid + BLOCK * j -> row = (tid >> LOW) | (j << (TB - LOW)): the thread part of the
+  // offset is computed once, the j part is wave-uniform (scalar registers)
   u64 off_tid = tid & ((1 << LOW) - 1);
 #pragma unroll
   for (int i = 0; i < TB - LOW && i < NH; ++i) off_tid |= (u64)((tid >> (LOW + i)) & 1) << a.h[i];
@@ -990,9 +774,9 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile_op(const T
   const bool live = NBLK == BLOCK || tid < NBLK;
   int gi = 0;
   while (gi < a.ngates) {
-    gi = __builtin_amdgcn_readfirstlane(gi);
+    gi = __builtin_amdgcn_readfirstlane(gi);          // keep the descriptor reads scalar
     const TileGate hd = a.g[gi++];                    // group header
-    const int s0 = hd.j0, s1 = hd.j1, s2 = hd.reg_mask;
+    const int s0 = hd.blk_mask & 15, s1 = (hd.blk_mask >> 4) & 15, s2 = (hd.blk_mask >> 8) & 15;
     const int ge = gi + hd.count;
     const unsigned tb = insert_zero(insert_zero(insert_zero((unsigned)tid, s0), s1), s2);
     const unsigned b0 = 1u << s0, b1 = 1u << s1, b2 = 1u << s2;
@@ -1006,9 +790,9 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile_op(const T
     for (int q0 = gi; q0 < ge; ++q0) {
       const int q = __builtin_amdgcn_readfirstlane(q0);
       const TileGate g = a.g[q];
-      const int mq = 4 * q;
       if ((base & g.outer_mask) != g.outer_mask) continue;
       if (!live || (tb & g.blk_mask) != g.blk_mask) continue;
+      const int mq = g.mat;   // the pool keeps 3 spare entries, so mq .. mq+3 is always readable
       const double2 u00 = a.mat[mq], u01 = a.mat[mq + 1], u10 = a.mat[mq + 2], u11 = a.mat[mq + 3];
       switch (g.opcode) {
         QS_CASES_1Q(OPC_DENSE1, QS_D1)
@@ -1048,6 +832,8 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile_op(const T
 }
 
 // ---- host planner: op list -> passes -> register groups ----------------------------------------
+enum { TG_DENSE1 = 0, TG_PHASE = 1, TG_DENSE2 = 2, TG_ANTI1 = 3, TG_SWAP1 = 4 };   // FusedOp::kind
+
 struct FusedOp {
   int kind;            // TG_DENSE1 / TG_ANTI1 / TG_SWAP1 (target, optional control), TG_PHASE, TG_DENSE2
   int target[2];       // 1q kinds: target[0]; TG_DENSE2: (qa, qb)
@@ -1134,25 +920,7 @@ template <int T>
 static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t stream, double alg_bytes) {
   const u64 ntiles = 1ull << (c->k - T);
   ProfileScope prof(6, alg_bytes, stream, 32.0 * (double)amps(c));
-  if (tuning().tile_persistent) {
-    // persistent grid: as many workgroups as stay resident, each walks tiles b, b + grid, ...
-    static int resident = 0;
-    if (!resident) {
-      int n = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile<T, true>, kTileThreads, 0) != hipSuccess || n < 1) n = 1;
-      resident = n;
-    }
-    const int per_cu = std::max(1, std::min(tuning().tile_wgs_per_cu, resident));
-    const u64 blocks = std::min<u64>(ntiles, (u64)tuning().num_cus * per_cu);
-    hipLaunchKernelGGL((k_tile<T, true>), dim3((unsigned)blocks), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
-  } else if constexpr (((1 << T) >> kGroupBits) <= kTileThreads) {
-    if (tuning().tile_opcode)
-      hipLaunchKernelGGL((k_tile_op<T>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
-    else
-      hipLaunchKernelGGL((k_tile<T, false>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
-  } else {
-    hipLaunchKernelGGL((k_tile<T, false>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
-  }
+  hipLaunchKernelGGL((k_tile<T>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a);
   prof.done(stream);
   HIP_TRY(hipGetLastError());
   return QSIM_OK;
@@ -1164,7 +932,6 @@ static int launch_tile_any(const TileArgs& a, int T, const qsim_chunk* c, hipStr
     case 9: return launch_tile<9>(a, c, stream, alg_bytes);
     case 10: return launch_tile<10>(a, c, stream, alg_bytes);
     case 11: return launch_tile<11>(a, c, stream, alg_bytes);
-    case 12: return launch_tile<12>(a, c, stream, alg_bytes);
   }
   return fail(QSIM_ERR_INVALID, "internal: tile size %d", T);
 }
@@ -1177,9 +944,22 @@ static inline u64 op_qmask(const FusedOp& o) {
   return m;
 }
 
+// Matrix-pool entries an op needs under the opcode it will get.
+static int pool_entries(const FusedOp& o) {
+  const bool sp = tuning().tile_special;
+  auto is = [&](int e, double re, double im) { return o.m[e].x == re && o.m[e].y == im; };
+  switch (o.kind) {
+    case TG_SWAP1: return 0;
+    case TG_PHASE: return (sp && (is(0, -1, 0) || is(0, 0, 1) || is(0, 0, -1))) ? 0 : 1;
+    case TG_ANTI1: return (sp && is(1, 0, -1) && is(2, 0, 1)) ? 0 : 4;
+    case TG_DENSE2: return 16;
+    default: return 4;
+  }
+}
+
 // Split one pass's ops (list order) into register groups of <= kGroupBits target tile bits and
-// emit the gate stream.  Returns false when the stream does not fit the kernel arguments; then
-// `taken` ops (a prefix-closed subset) were emitted and the caller re-queues the rest.
+// write the gate stream.  Ops that do not fit the argument budget stay un-emitted (they and
+// everything that depends on them wait for the next launch).
 static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_t>& members,
                         const std::vector<int>& high, int T, TileArgs* a, std::vector<char>* emitted) {
   const int low = kTileLow;
@@ -1188,15 +968,15 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
     for (size_t j = 0; j < high.size(); ++j) if (high[j] == b) return low + (int)j;
     return -1;
   };
-  auto entries_of = [](const FusedOp& o) { return o.kind == TG_DENSE2 ? 4 : 1; };   // a 4x4 = 4 matrix entries
   std::vector<char> done(members.size(), 0);
   size_t left = members.size();
   a->ngates = 0;
+  int pool = 0;                       // next free matrix entry; 3 spare entries stay at the end
   while (left) {
     std::vector<int> S;               // tile bits of this group
     std::vector<size_t> grp;          // indices into members
     u64 blocked = 0;
-    int entries = 0;
+    int pool_need = 0;
     for (size_t mi = 0; mi < members.size(); ++mi) {
       if (done[mi]) continue;
       const FusedOp& o = ops[members[mi]];
@@ -1209,12 +989,13 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
           if (std::find(S.begin(), S.end(), p) == S.end()) need[nneed++] = p;
         }
         if ((int)S.size() + nneed > kGroupBits) ok = false;
-        if (a->ngates + 1 + entries + entries_of(o) > kTileMaxGates) ok = false;
+        if (a->ngates + 1 + (int)grp.size() + 1 > kTileMaxGates || (int)grp.size() + 1 > 255) ok = false;
+        if (pool + pool_need + pool_entries(o) > kTileMaxMat - 3) ok = false;
       }
       if (!ok) { blocked |= qm; continue; }
       for (int t = 0; t < nneed; ++t) S.push_back(need[t]);
       grp.push_back(mi);
-      entries += entries_of(o);
+      pool_need += pool_entries(o);
     }
     if (grp.empty()) break;           // argument budget exhausted: the rest waits for the next launch
     // pad the group with the highest unused tile bits (high bits keep LDS accesses contiguous)
@@ -1227,57 +1008,46 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
     };
     TileGate hd;
     std::memset(&hd, 0, sizeof hd);
-    hd.kind = TG_GROUP; hd.j0 = (uint8_t)S[0]; hd.j1 = (uint8_t)S[1]; hd.reg_mask = (uint8_t)S[2];
-    hd.count = (uint8_t)entries;
+    hd.opcode = OPC_GROUP;
+    hd.count = (uint8_t)grp.size();
+    hd.blk_mask = (uint16_t)(S[0] | (S[1] << 4) | (S[2] << 8));
     a->g[a->ngates++] = hd;
     for (size_t mi : grp) {
       const FusedOp& o = ops[members[mi]];
       TileGate g;
       std::memset(&g, 0, sizeof g);
-      g.kind = (uint8_t)o.kind;
+      unsigned reg_mask = 0;
+      int ctrl_reg = -1;
       auto require_one = [&](int qubit) {      // a control / phase bit
         const int p = tile_pos(qubit);
         if (p < 0) { g.outer_mask |= 1ull << qubit; return; }
         const int r = reg_pos(p);
-        if (r >= 0) g.reg_mask |= (uint8_t)(1u << r);
+        if (r >= 0) { reg_mask |= 1u << r; ctrl_reg = r; }
         else g.blk_mask |= (uint16_t)(1u << p);
       };
+      auto is = [&](int e, double re, double im) { return o.m[e].x == re && o.m[e].y == im; };
+      const bool sp = tuning().tile_special;
       if (o.kind == TG_PHASE) {
         for (int t = 0; t < o.nbits; ++t) require_one(o.bits[t]);
+        const int fam = !sp ? OPC_PHASE : (is(0, -1, 0) ? OPC_PHASE_NEG : (is(0, 0, 1) ? OPC_PHASE_I : (is(0, 0, -1) ? OPC_PHASE_NI : OPC_PHASE)));
+        g.opcode = (uint8_t)(fam + reg_mask);
       } else if (o.kind == TG_DENSE2) {
-        g.j0 = (uint8_t)reg_pos(tile_pos(o.target[0]));
-        g.j1 = (uint8_t)reg_pos(tile_pos(o.target[1]));
+        g.opcode = (uint8_t)(OPC_DENSE2 + 3 * reg_pos(tile_pos(o.target[0])) + reg_pos(tile_pos(o.target[1])));
       } else {
-        g.j0 = (uint8_t)reg_pos(tile_pos(o.target[0]));
+        const int J = reg_pos(tile_pos(o.target[0]));
         if (o.control >= 0) require_one(o.control);
+        int fam = o.kind == TG_DENSE1 ? OPC_DENSE1 : (o.kind == TG_SWAP1 ? OPC_SWAP1 : OPC_ANTI1);
+        if (sp && o.kind == TG_DENSE1 && o.m[0].y == 0 && o.m[1].y == 0 && o.m[2].y == 0 && o.m[3].y == 0) fam = OPC_REAL1;
+        if (sp && o.kind == TG_ANTI1 && is(1, 0, -1) && is(2, 0, 1)) fam = OPC_YLIKE1;
+        g.opcode = (uint8_t)(fam + opc_1q_variant(J, ctrl_reg));
       }
-      {   // opcode for k_tile_op
-        int ctrl_reg = -1;
-        for (int r = 0; r < kGroupBits; ++r) if (g.reg_mask & (1u << r)) ctrl_reg = r;
-        auto is = [&](int e, double re, double im) { return o.m[e].x == re && o.m[e].y == im; };
-        if (o.kind == TG_PHASE) {
-          const bool sp = tuning().tile_special;
-          const int fam = !sp ? OPC_PHASE : (is(0, -1, 0) ? OPC_PHASE_NEG : (is(0, 0, 1) ? OPC_PHASE_I : (is(0, 0, -1) ? OPC_PHASE_NI : OPC_PHASE)));
-          g.opcode = (uint8_t)(fam + g.reg_mask);
-        } else if (o.kind == TG_DENSE2) {
-          g.opcode = (uint8_t)(OPC_DENSE2 + 3 * g.j0 + g.j1);
-        } else {
-          int fam = o.kind == TG_DENSE1 ? OPC_DENSE1 : (o.kind == TG_SWAP1 ? OPC_SWAP1 : OPC_ANTI1);
-          const bool sp = tuning().tile_special;
-          if (sp && o.kind == TG_DENSE1 && o.m[0].y == 0 && o.m[1].y == 0 && o.m[2].y == 0 && o.m[3].y == 0) fam = OPC_REAL1;
-          if (sp && o.kind == TG_ANTI1 && is(1, 0, -1) && is(2, 0, 1)) fam = OPC_YLIKE1;
-          g.opcode = (uint8_t)(fam + opc_1q_variant(g.j0, ctrl_reg));
-        }
+      const int need = pool_entries(o);
+      if (need) {
+        g.mat = (uint16_t)pool;
+        for (int e = 0; e < o.nm && e < need; ++e) a->mat[pool + e] = o.m[e];
+        pool += need;
       }
-      const int q = a->ngates;
-      for (int e = 0; e < o.nm; ++e) a->mat[4 * q + e] = o.m[e];
       a->g[a->ngates++] = g;
-      for (int pad = 1; pad < entries_of(o); ++pad) {
-        TileGate nop;
-        std::memset(&nop, 0, sizeof nop);
-        nop.kind = TG_NOP;
-        a->g[a->ngates++] = nop;
-      }
       done[mi] = 1;
       (*emitted)[mi] = 1;
       --left;
@@ -1291,7 +1061,7 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
 static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_passes) {
   const int k = c->k;
   const Tuning& tune = tuning();
-  const int T = k < tune.tile_bits ? k : tune.tile_bits;
+  const int T = k < kTileBitsMax ? k : kTileBitsMax;
   const int low = kTileLow;
   const int cap = T - low;                      // tile high-bit capacity
   std::vector<char> done(ops.size(), 0);
@@ -1328,8 +1098,7 @@ static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_pass
     TileArgs a;
     std::memset(&a, 0, sizeof a);
     a.amp = c->amp;
-    a.nh = (int)high.size();
-    for (int j = 0; j < a.nh; ++j) a.h[j] = (uint8_t)high[j];
+    for (size_t j = 0; j < high.size(); ++j) a.h[j] = (uint8_t)high[j];
     std::vector<char> emitted(members.size(), 0);
     emit_groups(ops, members, high, T, &a, &emitted);
     size_t n_emitted = 0;
