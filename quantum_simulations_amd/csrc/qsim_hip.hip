@@ -318,7 +318,9 @@ struct Tuning {
   int max_gates_per_pass = 128;
   int tile_special = 1;      // real / Y-like / -1 / +-i special-case opcodes in fused passes
   int debug_skip_gates = 0;  // QSIM_DEBUG_SKIP_GATES=1: tile passes move data but apply nothing (WRONG results)
+  int debug_stats = 0;       // QSIM_DEBUG_STATS=1: print gates / groups per pass to stderr
   Tuning() {
+    if (const char* e = getenv("QSIM_DEBUG_STATS")) debug_stats = atoi(e);
     if (const char* e = getenv("QSIM_SWZ_CUT")) swz_cut = atoi(e);
     if (const char* e = getenv("QSIM_NT")) force_nt = atoi(e);
     if (const char* e = getenv("QSIM_ITEMS")) items = atoi(e);
@@ -667,15 +669,23 @@ struct alignas(16) TileGate {   // 16 bytes: one s_load_dwordx4
   uint64_t outer_mask;     // absolute index bits outside the tile that must be 1
 };
 
+// The device reads a descriptor as ONE 128-bit scalar load (a struct copy is split by the
+// compiler into per-field loads that each wait for scalar memory: four round trips per gate).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+static_assert(sizeof(TileGate) == sizeof(u32x4), "descriptor = one dwordx4");
+
 struct TileArgs {
   double2* amp;
   int ngates;
   int pad;
   uint8_t h[16];           // ascending absolute positions of the tile's high bits
-  TileGate g[kTileMaxGates];
+  u32x4 g[kTileMaxGates];  // TileGate images
   double2 mat[kTileMaxMat];
 };
 static_assert(sizeof(TileArgs) <= 4096, "kernel arguments must fit 4 KiB");
+
+static inline void put_gate(TileArgs* a, int i, const TileGate& g) { std::memcpy(&a->g[i], &g, sizeof g); }
+static inline TileGate get_gate(const TileArgs* a, int i) { TileGate g; std::memcpy(&g, &a->g[i], sizeof g); return g; }
 
 __device__ __forceinline__ unsigned insert_zero(unsigned c, int p) {
   return ((c >> p) << (p + 1)) | (c & ((1u << p) - 1));
@@ -775,9 +785,10 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
   int gi = 0;
   while (gi < a.ngates) {
     gi = __builtin_amdgcn_readfirstlane(gi);          // keep the descriptor reads scalar
-    const TileGate hd = a.g[gi++];                    // group header
-    const int s0 = hd.blk_mask & 15, s1 = (hd.blk_mask >> 4) & 15, s2 = (hd.blk_mask >> 8) & 15;
-    const int ge = gi + hd.count;
+    const u32x4 hd = a.g[gi++];                       // group header: opcode | count << 8 | bits << 16
+    const unsigned hb = hd.x >> 16;
+    const int s0 = hb & 15, s1 = (hb >> 4) & 15, s2 = (hb >> 8) & 15;
+    const int ge = gi + ((hd.x >> 8) & 0xFF);
     const unsigned tb = insert_zero(insert_zero(insert_zero((unsigned)tid, s0), s1), s2);
     const unsigned b0 = 1u << s0, b1 = 1u << s1, b2 = 1u << s2;
     double2 x0, x1, x2, x3, x4, x5, x6, x7;
@@ -789,12 +800,14 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
     }
     for (int q0 = gi; q0 < ge; ++q0) {
       const int q = __builtin_amdgcn_readfirstlane(q0);
-      const TileGate g = a.g[q];
-      if ((base & g.outer_mask) != g.outer_mask) continue;
-      if (!live || (tb & g.blk_mask) != g.blk_mask) continue;
-      const int mq = g.mat;   // the pool keeps 3 spare entries, so mq .. mq+3 is always readable
+      const u32x4 g = a.g[q];                         // one s_load_dwordx4
+      const int mq = g.y & 0xFFFF;   // the pool keeps 3 spare entries, so mq .. mq+3 is always readable
       const double2 u00 = a.mat[mq], u01 = a.mat[mq + 1], u10 = a.mat[mq + 2], u11 = a.mat[mq + 3];
-      switch (g.opcode) {
+      const u64 outer = (u64)g.z | ((u64)g.w << 32);
+      if ((base & outer) != outer) continue;
+      const unsigned bm = g.x >> 16;
+      if (!live || (tb & bm) != bm) continue;
+      switch (g.x & 0xFF) {
         QS_CASES_1Q(OPC_DENSE1, QS_D1)
         QS_CASES_1Q(OPC_SWAP1, QS_SW)
         QS_CASES_1Q(OPC_ANTI1, QS_AN)
@@ -1011,7 +1024,7 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
     hd.opcode = OPC_GROUP;
     hd.count = (uint8_t)grp.size();
     hd.blk_mask = (uint16_t)(S[0] | (S[1] << 4) | (S[2] << 8));
-    a->g[a->ngates++] = hd;
+    put_gate(a, a->ngates++, hd);
     for (size_t mi : grp) {
       const FusedOp& o = ops[members[mi]];
       TileGate g;
@@ -1047,7 +1060,7 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
         for (int e = 0; e < o.nm && e < need; ++e) a->mat[pool + e] = o.m[e];
         pool += need;
       }
-      a->g[a->ngates++] = g;
+      put_gate(a, a->ngates++, g);
       done[mi] = 1;
       (*emitted)[mi] = 1;
       --left;
@@ -1111,6 +1124,11 @@ static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_pass
         done[members[mi]] = 1; --remaining; ++n_emitted;
       }
     if (!n_emitted) return fail(QSIM_ERR_INVALID, "internal: fused planner emitted nothing");
+    if (tune.debug_stats) {
+      int groups = 0;
+      for (int i = 0; i < a.ngates; ++i) groups += get_gate(&a, i).opcode == OPC_GROUP;
+      std::fprintf(stderr, "[qsim] pass %d: %zu gates, %d groups, %d entries\n", *n_passes, n_emitted, groups, a.ngates);
+    }
     if (tune.debug_skip_gates) a.ngates = 0;       // profiling aid: load -> LDS -> store only
     int rc = launch_tile_any(a, T, c, c->stream, alg_bytes);
     if (rc) return rc;
