@@ -631,11 +631,17 @@ static int gate_2q(const Group& g, int qa, int qb, const double* U, hipStream_t 
 #define QSIM_TILE_LOW 3
 #endif
 constexpr int kTileLow = QSIM_TILE_LOW;
-constexpr int kTileBitsMax = 11;       // 2^11 amplitudes = 32 KiB of LDS: 4-5 workgroups per CU
+#ifndef QSIM_TILE_BITS_MAX
+#define QSIM_TILE_BITS_MAX 11
+#endif
+constexpr int kTileBitsMax = QSIM_TILE_BITS_MAX;       // 2^11 amplitudes = 32 KiB of LDS: 4-5 workgroups per CU
 constexpr int kGroupBits = 3;
 constexpr int kGroupAmps = 1 << kGroupBits;
-constexpr int kTileThreads = 256;
-constexpr int kTileThreadBits = 8;
+#ifndef QSIM_TILE_THREADS
+#define QSIM_TILE_THREADS 256
+#endif
+constexpr int kTileThreads = QSIM_TILE_THREADS;
+constexpr int kTileThreadBits = kTileThreads == 128 ? 7 : 8;
 constexpr int kTileMaxGates = 144;     // entries incl. group headers  (2304 B of kernel arguments)
 constexpr int kTileMaxMat = 104;       // complex matrix pool          (1664 B)
 
@@ -931,12 +937,16 @@ static bool classify_op(int nq, const int32_t* q, const double* U, FusedOp* o) {
 
 template <int T>
 static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t stream, double alg_bytes) {
+  if constexpr (T > kTileBitsMax) {
+    return fail(QSIM_ERR_INVALID, "internal: tile size %d not built", T);
+  } else {
   const u64 ntiles = 1ull << (c->k - T);
   ProfileScope prof(6, alg_bytes, stream, 32.0 * (double)amps(c));
   hipLaunchKernelGGL((k_tile<T>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a);
   prof.done(stream);
   HIP_TRY(hipGetLastError());
   return QSIM_OK;
+  }
 }
 
 static int launch_tile_any(const TileArgs& a, int T, const qsim_chunk* c, hipStream_t stream, double alg_bytes) {
