@@ -517,7 +517,10 @@ static int launch_plan(const Plan& p, hipStream_t stream) {
     if (p.nm == 2 && p.nsh == 1) return nt ? launch_shuffle<2, 1, 2, true>(p, stream) : launch_shuffle<2, 1, 2, false>(p, stream);
     return fail(QSIM_ERR_INVALID, "internal: bad shuffle plan %d/%d", p.nm, p.nsh);
   }
-  int items = p.nm == 4 ? 1 : 2;
+  // work items per thread (profiles/r01e_tune_items_swz.txt): one 2- or 4-member item per thread
+  // is best up to removed bit 19 (0.77 vs 0.75 of peak); above it two items even out the
+  // q mod 4 pattern of the HBM address hash (0.70-0.77)
+  int items = p.nm == 4 ? 1 : ((p.nm == 2 && p.high_removed < 20) ? 1 : 2);
   bool swz = p.high_removed < t.swz_cut;
   if (!swz) items *= 2;
   if (t.items > 0) items = t.items;
@@ -538,9 +541,15 @@ static int gate_1q(const Group& g, int q, const double* U, hipStream_t stream) {
   Plan p;
   int rc;
   const bool diag = is_zero(U[2], U[3]) && is_zero(U[4], U[5]);
-  if (diag && is_one(U[0], U[1])) {
+  // A diagonal bit inside a 128-B line (q < kLaneCut) leaves no untouched lines: the subset form
+  // would still move every line, with partial-line accesses; the dense lane form streams whole
+  // lines non-temporally instead (6.3 -> 5.8 ms at n = 30).
+  const bool subline = q < g.k && q < kLaneCut;
+  if (diag && is_one(U[0], U[1]) && !subline) {
     if (is_one(U[6], U[7])) return QSIM_OK;  // identity
     rc = make_plan(g, nullptr, 0, &q, 1, U + 6, &p);  // scale the bit-set half by U11
+  } else if (diag && is_one(U[0], U[1]) && is_one(U[6], U[7])) {
+    return QSIM_OK;  // identity
   } else {
     rc = make_plan(g, &q, 1, nullptr, 0, U, &p);
   }
@@ -573,11 +582,11 @@ static int gate_2q(const Group& g, int qa, int qb, const double* U, hipStream_t 
     if (one(3, 3)) return QSIM_OK;  // identity
     const int fixed[2] = {qa, qb};
     rc = make_plan(g, nullptr, 0, fixed, 2, U + 2 * 15, &p);  // CZ / CR: quarter of the state
-  } else if (ctrl_a) {
+  } else if (ctrl_a && !(qa < g.k && qa < kLaneCut)) {   // (a sub-line control saves no traffic: dense form below)
     const double V[8] = {U[2 * 10], U[2 * 10 + 1], U[2 * 11], U[2 * 11 + 1],
                          U[2 * 14], U[2 * 14 + 1], U[2 * 15], U[2 * 15 + 1]};
     rc = make_plan(g, &qb, 1, &qa, 1, V, &p);  // CNOT / CY / CU: half of the state
-  } else if (ctrl_b) {
+  } else if (ctrl_b && !(qb < g.k && qb < kLaneCut)) {
     const double V[8] = {U[2 * 5], U[2 * 5 + 1], U[2 * 7], U[2 * 7 + 1],
                          U[2 * 13], U[2 * 13 + 1], U[2 * 15], U[2 * 15 + 1]};
     rc = make_plan(g, &qa, 1, &qb, 1, V, &p);

@@ -28,7 +28,7 @@ def timed(dev, fn, reps):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-    only = set(sys.argv[3].split(",")) if len(sys.argv) > 3 else None
+    only = set(sys.argv[3].split(";")) if len(sys.argv) > 3 else None
     dev = DeviceChunk.empty(n)
     dev.init_random(30)
     N = 1 << n
