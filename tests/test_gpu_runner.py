@@ -102,3 +102,18 @@ def test_v3_style_driver():
     ghz = Driver().run_circuit(golden_circuits()["fx_ghz_5"])
     d = Driver().get_state_dict(ghz)
     assert sorted(d) == [0, 31] and abs(d[0] - 2 ** -0.5) < 1e-12
+
+
+def test_pipeline_entry_point(runner):   # wenbo_engine/tests/test_nonlocal.py:214-235
+    from quantum_simulations_amd.runner import pipeline
+    for cname in ("fx_ghz_4", "fx_qft_4"):
+        cd = golden_circuits()[cname]
+        with tempfile.TemporaryDirectory() as td:
+            buf = pipeline.run(cd, td, chunk_size=4)
+            got = runner.collect_state(buf)
+            buf.close()
+        np.testing.assert_allclose(got, npz("states.npz")[cname], rtol=0, atol=1e-10)
+    with tempfile.TemporaryDirectory() as td:
+        buf = pipeline.run(golden_circuits()["fx_qft_4"], td, chunk_size=16, use_wal=False, use_fusion=True)
+        np.testing.assert_allclose(runner.collect_state(buf), npz("states.npz")["fx_qft_4"], rtol=0, atol=1e-10)
+        buf.close()
