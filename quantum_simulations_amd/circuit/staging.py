@@ -125,6 +125,10 @@ def _compute_local_qubits_heuristic(gates: list[dict], n: int, k: int) -> list[s
     re-layout, #stalled gates already local, index) and take the top k."""
     if not gates:
         return [set(range(min(k, n)))]
+    widest = max((len(non_insular_qubits(g)) for g in gates), default=0)
+    if widest > k:
+        # the reference never terminates here (no stage can ever hold the gate's qubits)
+        raise ValueError(f"staging needs k >= {widest} local qubits for this circuit, got k={k}")
     done = [False] * len(gates)
     is_local = [False] * n
     stages: list[set[int]] = []

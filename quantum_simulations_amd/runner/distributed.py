@@ -241,7 +241,7 @@ class DistributedEngine:
         relabeled = {"number_of_qubits": self.n,
                      "gates": [{"qubits": [l2p[q] for q in g["qubits"]], "gate": g["gate"],
                                 "params": g["params"]} for g in cd["gates"]]}
-        if self.staging:
+        if self.staging and self.k >= 2:   # (staging cannot hold a 2-qubit gate in fewer than 2 local qubits)
             steps, moved = atlas_stages(relabeled, self.k, method=self.staging_method,
                                         strict_order=True)
         else:

@@ -229,3 +229,57 @@ def test_strict_order_staging_is_exact(name, k):
         orc.apply_ops(psi, st["nonlocal_ops"])
     np.testing.assert_allclose(orc.permute_state(psi, l2p), orc.simulate(validate_circuit_dict(cd)),
                                rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_circuits_every_planner_is_exact(seed):
+    """Randomised: all 15 gate names, n = 5..8, every k: executing the emitted steps in order
+    (whole state as one chunk) reproduces the oracle for batch_levels, greedy staging and
+    strict-order heuristic staging."""
+    from oracle import dense_oracle as orc
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(5, 9))
+    names1 = ["H", "X", "Y", "Z", "S", "T", "RY", "R", "G"]
+    names2 = ["CNOT", "SWAP", "CZ", "CY", "CR", "CU"]
+    gates = []
+    for _ in range(40):
+        if rng.random() < 0.5:
+            nm = names1[int(rng.integers(len(names1)))]
+            g = {"qubits": [int(rng.integers(n))], "gate": nm}
+            if nm == "RY":
+                g["params"] = {"theta": float(rng.uniform(0, 6))}
+            elif nm == "R":
+                g["params"] = {"k": int(rng.integers(1, 6))}
+            elif nm == "G":
+                g["params"] = {"p": int(rng.integers(2, 6))}
+        else:
+            nm = names2[int(rng.integers(len(names2)))]
+            a, b = (int(x) for x in rng.choice(n, size=2, replace=False))
+            g = {"qubits": [a, b], "gate": nm}
+            if nm == "CR":
+                g["params"] = {"k": int(rng.integers(1, 6))}
+            elif nm == "CU":
+                g["params"] = {"U": gt.G(int(rng.integers(2, 5))), "exponent": int(rng.integers(1, 3))}
+        gates.append(g)
+    cd = {"number_of_qubits": n, "gates": gates}
+    want = orc.simulate(validate_circuit_dict(cd))
+
+    def run_steps(steps, l2p):
+        psi = np.zeros(1 << n, dtype=np.complex128)
+        psi[0] = 1.0
+        for st in steps:
+            orc.apply_ops(psi, st["local_ops"])
+            orc.apply_ops(psi, st["nonlocal_ops"])
+        return orc.permute_state(psi, l2p)
+
+    with pytest.raises(ValueError, match="k >= 2"):       # the reference loops forever here
+        staging.atlas_stages(cd, 1, method="heuristic")
+    for k in range(1, n):
+        plain = fusion.batch_levels(levelize(validate_circuit_dict(cd)), k)
+        np.testing.assert_allclose(run_steps(plain, list(range(n))), want, rtol=0, atol=1e-12)
+        for kw in ({"method": "greedy"}, {"method": "heuristic", "strict_order": True}):
+            if k < 2 and kw["method"] == "heuristic":
+                continue
+            steps, l2p = staging.atlas_stages(cd, k, **kw)
+            assert sorted(l2p) == list(range(n))
+            np.testing.assert_allclose(run_steps(steps, l2p), want, rtol=0, atol=1e-12, err_msg=f"k={k} {kw}")
