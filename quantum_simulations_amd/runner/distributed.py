@@ -146,7 +146,7 @@ class Plan:
 class DistributedEngine:
     def __init__(self, n_qubits: int, world: int, rank: int, local_rank: int = 0,
                  mode: str = "fused", backend=None, staging: bool = True,
-                 staging_method: str = "heuristic", init_process_group: bool = True):
+                 staging_method: str = "belady", init_process_group: bool = True):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist

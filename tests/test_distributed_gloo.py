@@ -109,7 +109,7 @@ def _run(world, n, staging_modes):
     assert not msgs and all(p.exitcode == 0 for p in procs), "\n".join(f"[rank {r}] {m}" for r, m in msgs)
 
 
-MODES = [(True, "heuristic"), (True, "greedy"), (False, "heuristic")]
+MODES = [(True, "belady"), (True, "heuristic"), (True, "greedy"), (False, "heuristic")]
 
 
 def test_world2_gloo():
@@ -121,4 +121,4 @@ def test_world4_gloo():
 
 
 def test_world8_gloo():
-    _run(8, 7, [(True, "heuristic"), (False, "heuristic")])
+    _run(8, 7, [(True, "belady"), (True, "heuristic"), (False, "heuristic")])

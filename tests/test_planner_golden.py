@@ -277,9 +277,23 @@ def test_random_circuits_every_planner_is_exact(seed):
     for k in range(1, n):
         plain = fusion.batch_levels(levelize(validate_circuit_dict(cd)), k)
         np.testing.assert_allclose(run_steps(plain, list(range(n))), want, rtol=0, atol=1e-12)
-        for kw in ({"method": "greedy"}, {"method": "heuristic", "strict_order": True}):
-            if k < 2 and kw["method"] == "heuristic":
+        for kw in ({"method": "greedy"}, {"method": "heuristic", "strict_order": True}, {"method": "belady"}):
+            if k < 2 and kw["method"] != "greedy":
                 continue
             steps, l2p = staging.atlas_stages(cd, k, **kw)
             assert sorted(l2p) == list(range(n))
             np.testing.assert_allclose(run_steps(steps, l2p), want, rtol=0, atol=1e-12, err_msg=f"k={k} {kw}")
+
+
+def test_belady_staging_needs_fewer_relayouts_on_the_bench_circuits():
+    """The xGMI-oriented method: identity start, farthest-next-use eviction -- fewer re-layout
+    steps than the Atlas heuristic on the seeded multi-GPU workloads (29/30 qubits, k = 28)."""
+    def relayouts(cd, k, method):
+        steps, _ = staging.atlas_stages(cd, k, method=method, strict_order=True)
+        return sum(1 for s in steps if s["nonlocal_ops"] and all(
+            len(q) == 2 and (q[0] < k) != (q[1] < k) and np.array_equal(U, gt.SWAP()) for q, U in s["nonlocal_ops"]))
+    for n in (29, 30):
+        cd = gen.random_1q_cx_circuit(n, depth=40)
+        assert relayouts(cd, 28, "belady") < relayouts(cd, 28, "heuristic")
+    steps, l2p = staging.atlas_stages(gen.generate_ghz_circuit(6), 6, method="belady")
+    assert l2p == list(range(6)) and len(steps) == 1           # all local: no staging
