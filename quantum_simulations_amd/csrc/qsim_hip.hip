@@ -319,8 +319,16 @@ struct Tuning {
   int tile_special = 1;      // real / Y-like / -1 / +-i special-case opcodes in fused passes
   int debug_skip_gates = 0;  // QSIM_DEBUG_SKIP_GATES=1: tile passes move data but apply nothing (WRONG results)
   int debug_stats = 0;       // QSIM_DEBUG_STATS=1: print gates / groups per pass to stderr
+  int tile_persistent = 0;   // resident grid + next-tile prefetch
+  int tile_wgs_per_cu = 8;   // upper bound for the persistent grid (the occupancy query decides)
+  int num_cus = 256;
   Tuning() {
     if (const char* e = getenv("QSIM_DEBUG_STATS")) debug_stats = atoi(e);
+    if (const char* e = getenv("QSIM_TILE_PERSIST")) tile_persistent = atoi(e);
+    if (const char* e = getenv("QSIM_TILE_WGS")) tile_wgs_per_cu = std::max(1, atoi(e));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) == hipSuccess && prop.multiProcessorCount > 0)
+      num_cus = prop.multiProcessorCount;
     if (const char* e = getenv("QSIM_SWZ_CUT")) swz_cut = atoi(e);
     if (const char* e = getenv("QSIM_NT")) force_nt = atoi(e);
     if (const char* e = getenv("QSIM_ITEMS")) items = atoi(e);
@@ -639,6 +647,9 @@ static int gate_2q(const Group& g, int qa, int qb, const double* U, hipStream_t 
 #ifndef QSIM_TILE_LOW
 #define QSIM_TILE_LOW 3
 #endif
+#ifndef QSIM_TILE_SWZ
+#define QSIM_TILE_SWZ 0
+#endif
 constexpr int kTileLow = QSIM_TILE_LOW;
 #ifndef QSIM_TILE_BITS_MAX
 #define QSIM_TILE_BITS_MAX 11
@@ -756,8 +767,11 @@ constexpr int tile_waves(int T) {
   return (160 * 1024) / ((1 << T) * 16) > 4 ? 4 : (160 * 1024) / ((1 << T) * 16);
 }
 
-template <int T>
-__global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const TileArgs a) {
+// PERSIST: a resident grid walks tiles b, b + gridDim.x, ...; the global loads of the next tile are
+// issued right after the current tile has been written to LDS, so they are in flight during the
+// whole gate phase (software pipelining across tiles).
+template <int T, bool PERSIST>
+__global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const TileArgs a, const unsigned ntiles) {
   constexpr int N = 1 << T;
   constexpr int LOW = kTileLow;
   constexpr int NH = T - LOW;                         // tile high bits
@@ -769,13 +783,16 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
   __shared__ double2 lds[N];
   const int tid = threadIdx.x;
   const bool elem_ok = N >= BLOCK || tid < N;         // tiny tiles: surplus threads idle
-  // global index of the tile's element 0: blockIdx enumerates the non-tile bits
-  u64 base = (u64)blockIdx.x << LOW;
+  // global index of a tile's element 0: the tile number enumerates the non-tile bits
+  auto tile_base = [&](unsigned tile_no) -> u64 {
+    u64 base = (u64)tile_no << LOW;
 #pragma unroll
-  for (int j = 0; j < NH; ++j) {
-    const int p = a.h[j];
-    base = ((base >> p) << (p + 1)) | (base & ((1ull << p) - 1));
-  }
+    for (int j = 0; j < NH; ++j) {
+      const int p = a.h[j];
+      base = ((base >> p) << (p + 1)) | (base & ((1ull << p) - 1));
+    }
+    return base;
+  };
   // element t = tid + BLOCK * j -> row = (tid >> LOW) | (j << (TB - LOW)): the thread part of the
   // offset is computed once, the j part is wave-uniform (scalar registers)
   u64 off_tid = tid & ((1 << LOW) - 1);
@@ -787,14 +804,23 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
     for (int i = TB - LOW; i < NH; ++i) o |= (u64)((j >> (i - (TB - LOW))) & 1) << a.h[i];
     return o;
   };
-  {
-    double2 v[PER];
+  unsigned tile = blockIdx.x;
+  u64 base = tile_base(tile);
+  double2 v[PER];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) if (elem_ok) v[j] = ld_amp<true>(a.amp + base + off_tid + off_j(j));
+  for (int j = 0; j < PER; ++j) if (elem_ok) v[j] = ld_amp<true>(a.amp + base + off_tid + off_j(j));
+  for (;;) {
 #pragma unroll
-    for (int j = 0; j < PER; ++j) if (elem_ok) lds[lds_slot(tid + BLOCK * j)] = v[j];
-  }
+  for (int j = 0; j < PER; ++j) if (elem_ok) lds[lds_slot(tid + BLOCK * j)] = v[j];
   __syncthreads();
+  const unsigned next = tile + gridDim.x;
+  const bool has_next = PERSIST && next < ntiles;
+  u64 next_base = 0;
+  if (PERSIST && has_next) {
+    next_base = tile_base(next);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) if (elem_ok) v[j] = ld_amp<true>(a.amp + next_base + off_tid + off_j(j));
+  }
 
   const bool live = NBLK == BLOCK || tid < NBLK;
   int gi = 0;
@@ -857,6 +883,10 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
 #pragma unroll
     for (int j = 0; j < PER; ++j) if (elem_ok) st_amp<true>(a.amp + base + off_tid + off_j(j), w[j]);
   }
+  if (!PERSIST || !has_next) break;
+  tile = next;
+  base = next_base;
+  }  // tile loop (each thread re-writes only the LDS slots it just read: no barrier needed)
 }
 
 // ---- host planner: op list -> passes -> register groups ----------------------------------------
@@ -951,7 +981,19 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   } else {
   const u64 ntiles = 1ull << (c->k - T);
   ProfileScope prof(6, alg_bytes, stream, 32.0 * (double)amps(c));
-  hipLaunchKernelGGL((k_tile<T>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a);
+  if (tuning().tile_persistent) {
+    static int resident = 0;            // workgroups per CU that registers and LDS admit
+    if (!resident) {
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile<T, true>, kTileThreads, 0) != hipSuccess || n < 1) n = 1;
+      resident = n;
+    }
+    const int per_cu = std::max(1, std::min(tuning().tile_wgs_per_cu, resident));
+    const u64 blocks = std::min<u64>(ntiles, (u64)tuning().num_cus * per_cu);
+    hipLaunchKernelGGL((k_tile<T, true>), dim3((unsigned)blocks), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
+  } else {
+    hipLaunchKernelGGL((k_tile<T, false>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
+  }
   prof.done(stream);
   HIP_TRY(hipGetLastError());
   return QSIM_OK;
@@ -1127,6 +1169,8 @@ static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_pass
     for (int b = low; (int)high.size() < cap && b < k; ++b)
       if (std::find(high.begin(), high.end(), b) == high.end()) high.push_back(b);
     std::sort(high.begin(), high.end());
+    if (tune.debug_skip_gates == 2) for (int j = 0; j < cap; ++j) high[j] = low + j;   // contiguous tiles (floor probe)
+    if (tune.debug_skip_gates == 3) for (int j = 0; j < cap; ++j) high[j] = k - cap + j; // far-strided tiles
     TileArgs a;
     std::memset(&a, 0, sizeof a);
     a.amp = c->amp;
