@@ -408,3 +408,26 @@ def test_closed_form_checker_with_staged_layout(hip):
     assert dev.max_abs_err_closed_form("ghz_qft", n, 0, [int(p) for p in l2p]) < 1e-12
     assert dev.max_abs_err_closed_form("ghz_qft", n, 0) > 1e-3      # wrong without the mapping
     dev.close()
+
+
+def test_config5_ghz_qft_33q_every_amplitude_on_one_gpu(hip):
+    """BASELINE config 5 at FULL size on one MI355X (2^33 amplitudes = 128 GiB, 594 gates, fused):
+    every amplitude within 1e-10 of the closed form, evaluated on the device."""
+    from quantum_simulations_amd.circuit.io import validate_circuit_dict
+    from quantum_simulations_amd.circuits import generate_ghz_qft
+    from quantum_simulations_amd.runner.engine import gate_ops
+    n = 33
+    try:
+        dev = hip.DeviceChunk.zero_state(n)
+    except MemoryError:
+        pytest.skip("device has less than 128 GiB free")
+    ops = gate_ops(validate_circuit_dict(generate_ghz_qft(n)))
+    assert len(ops) == 594
+    passes = dev.apply_ops(ops)
+    assert passes < 40
+    assert dev.max_abs_err_closed_form("ghz_qft", n) < ATOL_CIRCUIT
+    assert abs(dev.norm2() - 1.0) < 1e-11
+    off = (1 << 32) + 777
+    np.testing.assert_allclose(dev.download(off, 2048), orc.ghz_qft_closed_form(n, np.arange(off, off + 2048)),
+                               rtol=0, atol=ATOL_CIRCUIT)
+    dev.close()
