@@ -130,10 +130,15 @@ class DeviceChunk:
 
     def apply_ops(self, ops, fused: bool = True) -> int:
         """One pass: every (qubits, U) of `ops` in one C call.  `fused` groups them into LDS-tile
-        launches (order kept for ops sharing a qubit); returns the number of HBM round trips."""
-        if not ops:
+        launches (order kept for ops sharing a qubit); returns the number of HBM round trips.
+        `ops` may also be the tuple returned by `pack_ops` (plans that run repeatedly pack once)."""
+        if not len(ops):
             return 0
-        nq, qs, mats = pack_ops(ops)
+        if isinstance(ops, tuple) and len(ops) == 3 and isinstance(ops[0], np.ndarray):
+            nq, qs, mats = ops
+            ops = nq
+        else:
+            nq, qs, mats = pack_ops(ops)
         lib = _lib.load()
         fn = lib.qsim_apply_ops if fused else lib.qsim_apply_ops_unfused
         _lib.check(fn(self._h, len(ops), nq.ctypes.data_as(C.c_void_p), qs.ctypes.data_as(C.c_void_p),
