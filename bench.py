@@ -211,6 +211,12 @@ def main():
         # BASELINE config 3 / north-star target: H on every target of a 30-qubit state, per-gate
         # kernels (no fusion across the timed gates), fraction of the 8 TB/s peak per target
         out["sweep30"] = engine.sweep_1q(args.sweep_qubits)
+        sw = out["sweep30"]
+        out["roofline_per_gate_kernel"] = {
+            "bound": "hbm", "kernel": "k_gate<2> / k_gate_shuffle<1,1>: dense 1q, one launch per gate",
+            "achieved": round(sw["median_frac"] * HBM_PEAK_GBS, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": sw["median_frac"], "min_frac_over_targets": sw["min_frac"],
+            "workload": f"H on every target of a {sw['n_qubits']}-qubit state (32 B x 2^n per launch)"}
     if not args.no_cpu_baseline and world == 1:
         base, psi_cpu, done = cpu_baseline(circuit, args.cpu_seconds)
         out["cpu_baseline"] = base
