@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle stress (not part of the test suite): fused and per-gate op lists of
+every gate kind on n = 1..20 qubits, chunked runs with random chunk sizes, staged/unstaged.
+    python tools/stress_gpu.py [seconds]"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from oracle import dense_oracle as orc  # noqa: E402
+from quantum_simulations_amd.kernel.device import DeviceChunk  # noqa: E402
+from quantum_simulations_amd.runner import single_node  # noqa: E402
+from tests.test_gpu_kernels import _rand_state, _random_ops  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(2026)
+t0 = time.time()
+cases = 0
+worst = 0.0
+while time.time() - t0 < budget:
+    n = int(rng.integers(1, 21))
+    seed = int(rng.integers(1 << 30))
+    ops = _random_ops(n, int(rng.integers(1, 120)), seed) if n > 1 else [([0], orc.gate_matrix("H"))] * 5
+    psi0 = _rand_state(n, seed)
+    want = psi0.copy()
+    orc.apply_ops(want, ops)
+    dev = DeviceChunk.from_numpy(psi0)
+    for fused in (True, False):
+        dev.upload(psi0)
+        dev.apply_ops(ops, fused=fused)
+        err = float(np.max(np.abs(dev.download() - want)))
+        worst = max(worst, err)
+        assert err < 1e-10, (n, seed, fused, err)
+    dev.close()
+    if n >= 2 and n <= 12:   # chunked runner with a random chunk size, from |0..0>
+        names = ["H", "X", "T", "CNOT", "CZ", "SWAP", "CY"]
+        gates = []
+        for _ in range(int(rng.integers(1, 30))):
+            g = names[int(rng.integers(len(names)))]
+            if g in ("CNOT", "CZ", "SWAP", "CY"):
+                a, b = (int(x) for x in rng.choice(n, size=2, replace=False))
+                gates.append({"qubits": [a, b], "gate": g})
+            else:
+                gates.append({"qubits": [int(rng.integers(n))], "gate": g})
+        cd = {"number_of_qubits": n, "gates": gates}
+        ref = orc.simulate(cd)
+        cs = 1 << int(rng.integers(0, n + 1))
+        for kw in ({}, {"use_fusion": True}, {"use_staging": True, "staging_method": "belady"},
+                   {"use_staging": True, "staging_method": "greedy"}):
+            if kw.get("use_staging") and cs < 4 and kw["staging_method"] != "greedy":
+                continue
+            buf = single_node.run(cd, None, chunk_size=cs, **kw)
+            got = single_node.collect_state(buf)
+            if buf.log_to_phys:
+                from quantum_simulations_amd.circuit.staging import permute_state
+                got = permute_state(got, buf.log_to_phys)
+            buf.close()
+            err = float(np.max(np.abs(got - ref)))
+            worst = max(worst, err)
+            assert err < 1e-10, (n, cs, kw, err)
+    cases += 1
+print(f"stress ok: {cases} random cases in {time.time() - t0:.0f} s, worst |diff| = {worst:.2e}")
