@@ -104,6 +104,13 @@ int qsim_pack_bits(const qsim_chunk* src, int m, const int32_t* bits, int patter
 int qsim_unpack_bits(qsim_chunk* dst, int m, const int32_t* bits, int pattern,
                      const qsim_chunk* buf, uint64_t buf_offset_amps);
 
+/* All-to-all re-layout among the 2^g chunks of ONE device (chunks[c] = chunk index c): swaps
+ * local qubit local_bits[i] with chunk-index bit global_bits[i] for i < m (m <= 3) -- the merged
+ * form of a staging SWAP list ([p_out < k, p_in >= k], SWAP), staging.py:136-152.  Across GPUs
+ * the same exchange is driven by runner/distributed.py with qsim_pack_bits / RCCL.           */
+int qsim_swap_global_local(qsim_chunk* const* chunks, int n_chunks, const int32_t* global_bits,
+                           const int32_t* local_bits, int m);
+
 /* ---- synchronisation, reductions, timing ------------------------------------------- */
 int qsim_sync(qsim_chunk* c);
 int qsim_norm2(qsim_chunk* c, double* out);               /* sum |amp|^2               */

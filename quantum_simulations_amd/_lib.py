@@ -60,6 +60,7 @@ SIGNATURES = {
     "qsim_unpack_half": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "qsim_pack_bits": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_uint64]),
     "qsim_unpack_bits": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_uint64]),
+    "qsim_swap_global_local": (C.c_int, [_P, C.c_int, _P, _P, C.c_int]),
     "qsim_sync": (C.c_int, [_P]),
     "qsim_norm2": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "qsim_max_abs_err_closed_form": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64,

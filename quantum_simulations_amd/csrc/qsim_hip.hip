@@ -1298,6 +1298,18 @@ __global__ void k_unpack_bits(double2* __restrict__ dst, const double2* __restri
     dst[expand_index(j, npos, p0, p1, p2) | value_off] = ld_amp<true>(src + j);
 }
 
+// exchange slab (bits pos == a_off pattern) of chunk A with slab (bits pos == b_off pattern) of chunk B
+__global__ void k_swap_slabs(double2* __restrict__ a, double2* __restrict__ b, u64 n_slab,
+                             int npos, int p0, int p1, int p2, u64 a_off, u64 b_off) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n_slab; j += stride) {
+    const u64 e = expand_index(j, npos, p0, p1, p2);
+    const double2 x = a[e | a_off], y = b[e | b_off];
+    a[e | a_off] = y;
+    b[e | b_off] = x;
+  }
+}
+
 constexpr int kReduceBlocks = 2048;
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -1728,6 +1740,55 @@ int qsim_unpack_bits(qsim_chunk* dst, int m, const int32_t* bits, int pattern, c
   hipLaunchKernelGGL(k_unpack_bits, dim3(stream_grid(n_slab)), dim3(kBlock), 0, dst->stream,
                      dst->amp, (const double2*)buf->amp + buf_offset_amps, n_slab, m, pos[0], pos[1], pos[2], voff);
   HIP_TRY(hipGetLastError());
+  return QSIM_OK;
+}
+
+int qsim_swap_global_local(qsim_chunk* const* chunks, int n_chunks, const int32_t* global_bits,
+                           const int32_t* local_bits, int m) {
+  if (!chunks || !global_bits || !local_bits) return fail(QSIM_ERR_INVALID, "qsim_swap_global_local: null argument");
+  if (m < 1 || m > 3) return fail(QSIM_ERR_INVALID, "qsim_swap_global_local: 1..3 qubit pairs expected, got %d", m);
+  if (n_chunks < 2 || (n_chunks & (n_chunks - 1)) || n_chunks > 4096)
+    return fail(QSIM_ERR_INVALID, "qsim_swap_global_local: chunk count must be a power of two >= 2");
+  int rc = QSIM_OK;
+  for (int i = 0; i < n_chunks; ++i) {
+    if ((rc = check_chunk(chunks[i], "qsim_swap_global_local"))) return rc;
+    if (chunks[i]->k != chunks[0]->k || chunks[i]->device != chunks[0]->device)
+      return fail(QSIM_ERR_INVALID, "qsim_swap_global_local: chunks differ in size or device");
+  }
+  const int k = chunks[0]->k;
+  int g_bits = 0;
+  while ((1 << g_bits) < n_chunks) ++g_bits;
+  int sorted[3] = {0, 0, 0};
+  for (int i = 0; i < m; ++i) {
+    if (local_bits[i] < 0 || local_bits[i] >= k) return fail(QSIM_ERR_NONLOCAL, "qsim_swap_global_local: local bit %d is non-local for 2^%d chunks", local_bits[i], k);
+    if (global_bits[i] < 0 || global_bits[i] >= g_bits) return fail(QSIM_ERR_INVALID, "qsim_swap_global_local: chunk-index bit %d out of range", global_bits[i]);
+    for (int j = 0; j < i; ++j)
+      if (local_bits[j] == local_bits[i] || global_bits[j] == global_bits[i])
+        return fail(QSIM_ERR_INVALID, "qsim_swap_global_local: repeated bit");
+    sorted[i] = local_bits[i];
+  }
+  std::sort(sorted, sorted + m);
+  HIP_TRY(hipSetDevice(chunks[0]->device));
+  const u64 n_slab = 1ull << (k - m);
+  auto local_offset = [&](int pattern) {
+    u64 off = 0;
+    for (int i = 0; i < m; ++i) if ((pattern >> i) & 1) off |= 1ull << local_bits[i];
+    return off;
+  };
+  for (int c = 0; c < n_chunks; ++c) {
+    int mine = 0;                                   // pattern of this chunk's swapped index bits
+    for (int i = 0; i < m; ++i) mine |= ((c >> global_bits[i]) & 1) << i;
+    for (int d = 0; d < (1 << m); ++d) {
+      if (d == mine) continue;
+      int peer = c;
+      for (int i = 0; i < m; ++i) peer = (peer & ~(1 << global_bits[i])) | (((d >> i) & 1) << global_bits[i]);
+      if (peer < c) continue;                       // each unordered pair once
+      hipLaunchKernelGGL(k_swap_slabs, dim3(stream_grid(n_slab)), dim3(kBlock), 0, chunks[0]->stream,
+                         chunks[c]->amp, chunks[peer]->amp, n_slab, m, sorted[0], sorted[1], sorted[2],
+                         local_offset(d), local_offset(mine));
+      HIP_TRY(hipGetLastError());
+    }
+  }
   return QSIM_OK;
 }
 

@@ -66,3 +66,15 @@ def apply_2q_quad(c00, c01, c10, c11, U: np.ndarray) -> None:
     m, p = _mat_ptr(U, 4)
     _on_device([c00, c01, c10, c11], lambda d: _lib.check(
         _lib.load().qsim_apply_2q_quad(d[0]._h, d[1]._h, d[2]._h, d[3]._h, p)))
+
+
+def swap_global_local(chunks, global_bits, local_bits) -> None:
+    """Re-layout among ALL chunks of one device: local qubit local_bits[i] <-> chunk-index bit
+    global_bits[i] (the merged form of a staging SWAP list); `chunks[c]` is chunk index c."""
+    if len(global_bits) != len(local_bits) or not global_bits:
+        raise ValueError("need as many chunk-index bits as local bits")
+    arr = (C.c_void_p * len(chunks))(*[c._h for c in chunks])
+    gb = np.asarray(global_bits, dtype=np.int32)
+    lb = np.asarray(local_bits, dtype=np.int32)
+    _lib.check(_lib.load().qsim_swap_global_local(arr, len(chunks), gb.ctypes.data_as(C.c_void_p),
+                                                  lb.ctypes.data_as(C.c_void_p), len(gb)))

@@ -98,7 +98,33 @@ def _apply_step(state: DeviceChunk, chunks: list[DeviceChunk], local_ops, nonloc
     if local_ops:
         state.apply_ops(local_ops)
     if nonlocal_ops:
-        _process_nonlocal_groups(chunks, nonlocal_ops, k)
+        pairs = _relayout_pairs(nonlocal_ops, k)
+        if pairs is not None and len(pairs) <= 3:   # a staging SWAP list: ONE all-to-all re-layout
+            gpu_nonlocal.swap_global_local(chunks, [hi - k for _, hi in pairs], [lo for lo, _ in pairs])
+        else:
+            _process_nonlocal_groups(chunks, nonlocal_ops, k)
+
+
+_SWAP_U = None
+
+
+def _relayout_pairs(nonlocal_ops, k: int):
+    """[(local bit, global bit)] when every op is a SWAP between one local and one non-local qubit
+    on pairwise different bits (what staging emits, staging.py:136-152); else None."""
+    global _SWAP_U
+    if _SWAP_U is None:
+        from quantum_simulations_amd.kernel import gates as gate_table
+        _SWAP_U = gate_table.SWAP()
+    pairs, used = [], set()
+    for qs, U in nonlocal_ops:
+        if len(qs) != 2 or U.shape != (4, 4) or not np.array_equal(U, _SWAP_U):
+            return None
+        lo, hi = min(qs), max(qs)
+        if not (lo < k <= hi) or lo in used or hi in used:
+            return None
+        used.update((lo, hi))
+        pairs.append((lo, hi))
+    return pairs
 
 
 def _process_nonlocal_groups(chunks, nonlocal_ops, k: int) -> None:
