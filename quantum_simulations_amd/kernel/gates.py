@@ -8,8 +8,8 @@ Same gate set, names, parameters and matrix conventions as the reference
     row/col = 2*bit(qubits[0]) + bit(qubits[1]); qubits[0] is the control.
 
 The matrices are built on the host (32 B / 256 B each) and handed to the HIP
-kernels as kernel arguments; `classify_1q` / `classify_2q` tell the launcher
-which specialised kernel (diagonal, controlled, swap) moves the fewest HBM bytes.
+kernels as kernel arguments; the library inspects their zero/one pattern to pick
+the specialised kernel (diagonal, controlled, swap) that moves the fewest HBM bytes.
 """
 from __future__ import annotations
 
