@@ -68,6 +68,7 @@ struct qsim_chunk {
   bool have_events;
   double* scratch;       // reduction workspace (lazily allocated, owned)
   int last_passes;       // HBM passes of the last qsim_apply_ops
+  u64 span_bytes;        // size of the allocation the chunk lives in (cache-policy choice)
 };
 
 static const int kMaxDevices = 16;
@@ -302,6 +303,7 @@ struct Plan {
   double2 u[16];            // (nm << nsh)^2 canonical matrix
   int low_removed;          // lowest removed index bit (64 if none)
   int high_removed;         // highest removed index bit (-1 if none)
+  bool resident;            // the whole state fits the Infinity Cache: plain (cacheable) accesses
 };
 
 static inline bool is_zero(double re, double im) { return re == 0.0 && im == 0.0; }
@@ -322,7 +324,12 @@ struct Tuning {
   int tile_persistent = 0;   // resident grid + next-tile prefetch
   int tile_wgs_per_cu = 8;   // upper bound for the persistent grid (the occupancy query decides)
   int num_cus = 256;
+  // States up to this size stay in the 256 MiB Infinity Cache between launches when accessed with
+  // the default cache policy (tools/mall_probe.hip: 8.5-8.8 TB/s r+w for a 128-256 MiB region vs
+  // 5.5 streaming); the NT policy bypasses it (6.0-6.2 at every size), so NT is for larger states.
+  u64 mall_bytes = 256ull << 20;
   Tuning() {
+    if (const char* e = getenv("QSIM_MALL_BYTES")) mall_bytes = strtoull(e, nullptr, 10);
     if (const char* e = getenv("QSIM_DEBUG_STATS")) debug_stats = atoi(e);
     if (const char* e = getenv("QSIM_TILE_PERSIST")) tile_persistent = atoi(e);
     if (const char* e = getenv("QSIM_TILE_WGS")) tile_wgs_per_cu = std::max(1, atoi(e));
@@ -395,6 +402,18 @@ struct ProfileScope {  // RAII around one launch
   }
 };
 
+// Do the allocations behind a group fit the Infinity Cache?
+static bool group_resident(const Group& g) {
+  bool one_parent = g.c[0]->parent != nullptr;
+  u64 bytes = 0;
+  for (int i = 0; i < g.n; ++i) {
+    bytes += g.c[i]->span_bytes;
+    one_parent = one_parent && g.c[i]->parent == g.c[0]->parent;
+  }
+  if (one_parent) bytes = g.c[0]->span_bytes;
+  return bytes <= tuning().mall_bytes;
+}
+
 // Resolve a virtual offset (bits >= k select the chunk) to a device pointer.
 static double2* resolve(const Group& g, u64 voff) {
   const u64 ci = voff >> g.k;
@@ -412,6 +431,7 @@ static int make_plan(const Group& g, const int* targets, int nt, const int* fixe
   }
   p->nm = 1 << nr_bits;
   p->nsh = nsh;
+  p->resident = group_resident(g);
   int removed[4];
   int nr = 0;
   for (int j = 0; j < nt; ++j) if (!lane_t[j] && targets[j] < g.k) removed[nr++] = targets[j];
@@ -516,7 +536,7 @@ static int launch_reg_items(const Plan& p, int items, bool nt, bool swz, hipStre
 static int launch_plan(const Plan& p, hipStream_t stream) {
   const Tuning& t = tuning();
   // NT only when every wave instruction covers whole 128-B lines
-  bool nt = p.low_removed >= 3;
+  bool nt = p.low_removed >= 3 && !p.resident;
   if (t.force_nt >= 0) nt = t.force_nt != 0;
   if (p.count > (1ull << 40)) return fail(QSIM_ERR_INVALID, "grid too large");
   if (p.nsh > 0) {
@@ -609,6 +629,7 @@ static int gate_2q(const Group& g, int qa, int qb, const double* U, hipStream_t 
     std::sort(removed, removed + nr);
     p.nm = 2;
     p.nsh = 0;
+    p.resident = group_resident(g);
     p.lane_bit[0] = p.lane_bit[1] = 0;
     p.npos = nr;
     for (int i = 0; i < 3; ++i) p.pos[i] = i < nr ? removed[i] : 0;
@@ -656,7 +677,6 @@ constexpr int kTileLow = QSIM_TILE_LOW;
 #endif
 constexpr int kTileBitsMax = QSIM_TILE_BITS_MAX;       // 2^11 amplitudes = 32 KiB of LDS: 4-5 workgroups per CU
 constexpr int kGroupBits = 3;
-constexpr int kGroupAmps = 1 << kGroupBits;
 #ifndef QSIM_TILE_THREADS
 #define QSIM_TILE_THREADS 256
 #endif
@@ -770,7 +790,7 @@ constexpr int tile_waves(int T) {
 // PERSIST: a resident grid walks tiles b, b + gridDim.x, ...; the global loads of the next tile are
 // issued right after the current tile has been written to LDS, so they are in flight during the
 // whole gate phase (software pipelining across tiles).
-template <int T, bool PERSIST>
+template <int T, bool PERSIST, bool NT>
 __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const TileArgs a, const unsigned ntiles) {
   constexpr int N = 1 << T;
   constexpr int LOW = kTileLow;
@@ -808,7 +828,7 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
   u64 base = tile_base(tile);
   double2 v[PER];
 #pragma unroll
-  for (int j = 0; j < PER; ++j) if (elem_ok) v[j] = ld_amp<true>(a.amp + base + off_tid + off_j(j));
+  for (int j = 0; j < PER; ++j) if (elem_ok) v[j] = ld_amp<NT>(a.amp + base + off_tid + off_j(j));
   for (;;) {
 #pragma unroll
   for (int j = 0; j < PER; ++j) if (elem_ok) lds[lds_slot(tid + BLOCK * j)] = v[j];
@@ -819,7 +839,7 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
   if (PERSIST && has_next) {
     next_base = tile_base(next);
 #pragma unroll
-    for (int j = 0; j < PER; ++j) if (elem_ok) v[j] = ld_amp<true>(a.amp + next_base + off_tid + off_j(j));
+    for (int j = 0; j < PER; ++j) if (elem_ok) v[j] = ld_amp<NT>(a.amp + next_base + off_tid + off_j(j));
   }
 
   const bool live = NBLK == BLOCK || tid < NBLK;
@@ -881,7 +901,7 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
 #pragma unroll
     for (int j = 0; j < PER; ++j) if (elem_ok) w[j] = lds[lds_slot(tid + BLOCK * j)];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) if (elem_ok) st_amp<true>(a.amp + base + off_tid + off_j(j), w[j]);
+    for (int j = 0; j < PER; ++j) if (elem_ok) st_amp<NT>(a.amp + base + off_tid + off_j(j), w[j]);
   }
   if (!PERSIST || !has_next) break;
   tile = next;
@@ -985,14 +1005,17 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
     static int resident = 0;            // workgroups per CU that registers and LDS admit
     if (!resident) {
       int n = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile<T, true>, kTileThreads, 0) != hipSuccess || n < 1) n = 1;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile<T, true, true>, kTileThreads, 0) != hipSuccess || n < 1) n = 1;
       resident = n;
     }
     const int per_cu = std::max(1, std::min(tuning().tile_wgs_per_cu, resident));
     const u64 blocks = std::min<u64>(ntiles, (u64)tuning().num_cus * per_cu);
-    hipLaunchKernelGGL((k_tile<T, true>), dim3((unsigned)blocks), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
+    hipLaunchKernelGGL((k_tile<T, true, true>), dim3((unsigned)blocks), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
   } else {
-    hipLaunchKernelGGL((k_tile<T, false>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
+    bool nt = c->span_bytes > tuning().mall_bytes;
+    if (tuning().force_nt >= 0) nt = tuning().force_nt != 0;
+    if (nt) hipLaunchKernelGGL((k_tile<T, false, true>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
+    else hipLaunchKernelGGL((k_tile<T, false, false>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
   }
   prof.done(stream);
   HIP_TRY(hipGetLastError());
@@ -1428,6 +1451,7 @@ int qsim_create(int device, int n_local_qubits, qsim_chunk** out) {
   c->amp = p;
   c->stream = s;
   c->owns_memory = true;
+  c->span_bytes = sizeof(double2) << n_local_qubits;
   *out = c;
   return QSIM_OK;
 }
@@ -1448,6 +1472,7 @@ int qsim_create_view(qsim_chunk* parent, uint64_t offset_amps, int n_local_qubit
   c->stream = parent->stream;
   c->owns_memory = false;
   c->parent = parent;
+  c->span_bytes = parent->span_bytes;
   *out = c;
   return QSIM_OK;
 }
@@ -1462,6 +1487,7 @@ int qsim_wrap(int device, void* device_ptr, int n_local_qubits, void* stream, qs
   c->amp = (double2*)device_ptr;
   c->stream = (hipStream_t)stream;
   c->owns_memory = false;
+  c->span_bytes = sizeof(double2) << n_local_qubits;
   *out = c;
   return QSIM_OK;
 }

@@ -14,8 +14,7 @@ ATOL_KERNEL = 1e-12
 ATOL_CIRCUIT = 1e-10
 
 
-@pytest.fixture(scope="module")
-def hip():
+def _hip_namespace():
     from quantum_simulations_amd.kernel import gpu_local, gpu_nonlocal, ref_dense
     from quantum_simulations_amd.kernel.device import DeviceChunk, device_count
     assert device_count() >= 1
@@ -25,6 +24,11 @@ def hip():
     ns = NS()
     ns.local, ns.nonlocal_, ns.ref_dense, ns.DeviceChunk = gpu_local, gpu_nonlocal, ref_dense, DeviceChunk
     return ns
+
+
+@pytest.fixture(scope="module")
+def hip():
+    return _hip_namespace()
 
 
 def _rand_state(n, seed):
@@ -431,3 +435,26 @@ def test_config5_ghz_qft_33q_every_amplitude_on_one_gpu(hip):
     np.testing.assert_allclose(dev.download(off, 2048), orc.ghz_qft_closed_form(n, np.arange(off, off + 2048)),
                                rtol=0, atol=ATOL_CIRCUIT)
     dev.close()
+
+
+def test_streaming_cache_policy_on_small_states():
+    """States <= 256 MiB use plain (Infinity-Cache resident) accesses, larger ones the
+    non-temporal streaming forms; the environment knob is read once per process, so the
+    streaming instantiations are exercised on small states in ONE child process that re-runs
+    the target/pair sweeps and the fused passes of this module."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import tests.test_gpu_kernels as t\n"
+        "h = t._hip_namespace()\n"
+        "for n in (5, 9, 14): t.test_every_1q_target_vs_oracle(h, n)\n"
+        "for n in (3, 7, 11): t.test_every_2q_pair_vs_oracle(h, n)\n"
+        "for n in (9, 12, 16): t.test_fused_tile_passes_vs_oracle(h, n)\n"
+        "t.test_nonlocal_vs_oracle_all_local_bits(h)\n"
+        "print('STREAMING-POLICY-OK')\n")
+    env = dict(os.environ, QSIM_MALL_BYTES="0", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "STREAMING-POLICY-OK" in out.stdout, out.stdout + out.stderr
