@@ -740,17 +740,40 @@ __device__ __forceinline__ unsigned insert_zero(unsigned c, int p) {
 // conflicts are not what limits the gate phase)
 __device__ __forceinline__ unsigned lds_slot(unsigned t) { return t ^ ((t >> 4) & 15u); }
 
-#define QS_D1(A, B) { const double2 a_ = A, b_ = B; A = cfma(u01, b_, cmul(u00, a_)); B = cfma(u11, b_, cmul(u10, a_)); }
-#define QS_AN(A, B) { const double2 a_ = A, b_ = B; A = cmul(u01, b_); B = cmul(u10, a_); }
-#define QS_SW(A, B) { const double2 t_ = A; A = B; B = t_; }
-#define QS_DR(A, B) { const double2 a_ = A, b_ = B;                                               \
-    A = make_double2(fma(u01.x, b_.x, u00.x * a_.x), fma(u01.x, b_.y, u00.x * a_.y));               \
-    B = make_double2(fma(u11.x, b_.x, u10.x * a_.x), fma(u11.x, b_.y, u10.x * a_.y)); }
-#define QS_YL(A, B) { const double2 a_ = A, b_ = B; A = make_double2(b_.y, -b_.x); B = make_double2(-a_.y, a_.x); }
-#define QS_PH(A) { A = cmul(u00, A); }
-#define QS_PN(A) { A = make_double2(-A.x, -A.y); }
-#define QS_PI(A) { A = make_double2(-A.y, A.x); }
-#define QS_PM(A) { A = make_double2(A.y, -A.x); }
+// Every case of the gate switch must leave x0..x7 in the registers it found them in: when a case
+// defines a new value while the old one is still live the register allocator gives the whole PHI
+// web of the switch a second register set and EVERY gate pays 32 v_mov_b64 (2/3 of the VALU work of
+// a pass, r01f ISA audit).  So the last instruction of each output is inline asm whose destination
+// is tied ("+v") to the old register; partial sums live in ordinary temporaries.
+#define QS_IP_FMA(D, S, V, C)  asm volatile("v_fma_f64 %0, %1, %2, %3" : "+v"(D) : "s"(S), "v"(V), "v"(C))    /* D = S*V + C  */
+#define QS_IP_FNMA(D, S, V, C) asm volatile("v_fma_f64 %0, -%1, %2, %3" : "+v"(D) : "s"(S), "v"(V), "v"(C))   /* D = -S*V + C */
+#define QS_IP_MOV(D, V)        asm volatile("v_mov_b64 %0, %1" : "+v"(D) : "v"(V))                              /* D = V        */
+#define QS_IP_NEG(D, V)        asm volatile("v_mul_f64 %0, -1.0, %1" : "+v"(D) : "v"(V))                        /* D = -V       */
+#define QS_D1(A, B) {                                                                               \
+    double t0_ = fma(-u00.y, A.y, u00.x * A.x), t1_ = fma(u00.y, A.x, u00.x * A.y);                 \
+    double t2_ = fma(-u10.y, A.y, u10.x * A.x), t3_ = fma(u10.y, A.x, u10.x * A.y);                 \
+    t0_ = fma(u01.x, B.x, t0_); t1_ = fma(u01.x, B.y, t1_);                                         \
+    t2_ = fma(-u11.y, B.y, fma(u11.x, B.x, t2_)); t3_ = fma(u11.x, B.y, t3_);                       \
+    QS_IP_FNMA(A.x, u01.y, B.y, t0_); QS_IP_FMA(A.y, u01.y, B.x, t1_);                              \
+    QS_IP_FMA(B.y, u11.y, B.x, t3_); QS_IP_MOV(B.x, t2_); }
+#define QS_AN(A, B) {                                                                               \
+    const double t2_ = fma(-u10.y, A.y, u10.x * A.x), t3_ = fma(u10.y, A.x, u10.x * A.y);           \
+    const double t0_ = u01.x * B.x, t1_ = u01.x * B.y;                                              \
+    QS_IP_FNMA(A.x, u01.y, B.y, t0_); QS_IP_FMA(A.y, u01.y, B.x, t1_);                              \
+    QS_IP_MOV(B.x, t2_); QS_IP_MOV(B.y, t3_); }
+#define QS_SW(A, B) { const double t0_ = A.x, t1_ = A.y;                                            \
+    QS_IP_MOV(A.x, B.x); QS_IP_MOV(A.y, B.y); QS_IP_MOV(B.x, t0_); QS_IP_MOV(B.y, t1_); }
+#define QS_DR(A, B) {                                                                               \
+    const double tx_ = u00.x * A.x, ty_ = u00.x * A.y, sx_ = u10.x * A.x, sy_ = u10.x * A.y;        \
+    QS_IP_FMA(A.x, u01.x, B.x, tx_); QS_IP_FMA(A.y, u01.x, B.y, ty_);                               \
+    QS_IP_FMA(B.x, u11.x, B.x, sx_); QS_IP_FMA(B.y, u11.x, B.y, sy_); }
+#define QS_YL(A, B) { const double t0_ = A.x, t1_ = A.y;                                            \
+    QS_IP_MOV(A.x, B.y); QS_IP_NEG(A.y, B.x); QS_IP_NEG(B.x, t1_); QS_IP_MOV(B.y, t0_); }
+#define QS_PH(A) { const double p_ = u00.y * A.x, t_ = u00.x * A.x;                                 \
+    QS_IP_FNMA(A.x, u00.y, A.y, t_); QS_IP_FMA(A.y, u00.x, A.y, p_); }
+#define QS_PN(A) { QS_IP_NEG(A.x, A.x); QS_IP_NEG(A.y, A.y); }
+#define QS_PI(A) { const double t_ = A.x; QS_IP_NEG(A.x, A.y); QS_IP_MOV(A.y, t_); }
+#define QS_PM(A) { const double t_ = A.x; QS_IP_MOV(A.x, A.y); QS_IP_NEG(A.y, t_); }
 // register pairs (bit J clear / set) of each 1q variant
 #define QS_PAIRS_0(OP) OP(x0, x1) OP(x2, x3) OP(x4, x5) OP(x6, x7)
 #define QS_PAIRS_1(OP) OP(x0, x2) OP(x1, x3) OP(x4, x6) OP(x5, x7)
@@ -776,10 +799,12 @@ __device__ __forceinline__ unsigned lds_slot(unsigned t) { return t ^ ((t >> 4) 
 // 4x4 on (v00, v01 = qb set, v10 = qa set, v11); the 16 entries are read where they are used
 #define QS_D2(V0, V1, V2, V3) {                                                                         \
     const double2 a_ = V0, b_ = V1, c_ = V2, d_ = V3;                                                   \
-    V0 = cfma(a.mat[mq + 3], d_, cfma(a.mat[mq + 2], c_, cfma(a.mat[mq + 1], b_, cmul(a.mat[mq + 0], a_))));     \
-    V1 = cfma(a.mat[mq + 7], d_, cfma(a.mat[mq + 6], c_, cfma(a.mat[mq + 5], b_, cmul(a.mat[mq + 4], a_))));     \
-    V2 = cfma(a.mat[mq + 11], d_, cfma(a.mat[mq + 10], c_, cfma(a.mat[mq + 9], b_, cmul(a.mat[mq + 8], a_))));   \
-    V3 = cfma(a.mat[mq + 15], d_, cfma(a.mat[mq + 14], c_, cfma(a.mat[mq + 13], b_, cmul(a.mat[mq + 12], a_)))); }
+    const double2 r0_ = cfma(a.mat[mq + 3], d_, cfma(a.mat[mq + 2], c_, cfma(a.mat[mq + 1], b_, cmul(a.mat[mq + 0], a_))));     \
+    const double2 r1_ = cfma(a.mat[mq + 7], d_, cfma(a.mat[mq + 6], c_, cfma(a.mat[mq + 5], b_, cmul(a.mat[mq + 4], a_))));     \
+    const double2 r2_ = cfma(a.mat[mq + 11], d_, cfma(a.mat[mq + 10], c_, cfma(a.mat[mq + 9], b_, cmul(a.mat[mq + 8], a_))));   \
+    const double2 r3_ = cfma(a.mat[mq + 15], d_, cfma(a.mat[mq + 14], c_, cfma(a.mat[mq + 13], b_, cmul(a.mat[mq + 12], a_)))); \
+    QS_IP_MOV(V0.x, r0_.x); QS_IP_MOV(V0.y, r0_.y); QS_IP_MOV(V1.x, r1_.x); QS_IP_MOV(V1.y, r1_.y);     \
+    QS_IP_MOV(V2.x, r2_.x); QS_IP_MOV(V2.y, r2_.y); QS_IP_MOV(V3.x, r3_.x); QS_IP_MOV(V3.y, r3_.y); }
 
 // min waves per SIMD asked of the register allocator: what the LDS footprint admits, capped at 4
 // (5 forces spills at T = 11 and measured slower)
@@ -866,8 +891,16 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
       const double2 u00 = a.mat[mq], u01 = a.mat[mq + 1], u10 = a.mat[mq + 2], u11 = a.mat[mq + 3];
       const u64 outer = (u64)g.z | ((u64)g.w << 32);
       if ((base & outer) != outer) continue;
+      // Lane predicate (control / diagonal bits that are tile bits outside the group).  EXEC is
+      // narrowed by hand: a compiler-managed divergent region makes StructurizeCFG rewrite the
+      // (uniform) opcode switch into flow blocks whose PHIs double-buffer x0..x7 (see QS_IP_*).
+      // Everything up to the restore is VALU on x0..x7 / case-local temporaries + scalar branches.
       const unsigned bm = g.x >> 16;
-      if (!live || (tb & bm) != bm) continue;
+      const u64 act = __builtin_amdgcn_ballot_w64(live && (tb & bm) == bm);
+      if (act == 0) continue;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_mov_b64 exec, %0" : : "s"(act) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
       switch (g.x & 0xFF) {
         QS_CASES_1Q(OPC_DENSE1, QS_D1)
         QS_CASES_1Q(OPC_SWAP1, QS_SW)
@@ -886,6 +919,9 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
         case OPC_DENSE2 + 7: QS_D2(x0, x2, x4, x6) QS_D2(x1, x3, x5, x7) break;   // qa = bit 2, qb = bit 1
         default: break;
       }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_mov_b64 exec, -1" : : : "memory");   // whole waves: blockDim is a multiple of 64
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (live) {
       lds[lds_slot(tb)] = x0;            lds[lds_slot(tb | b0)] = x1;
@@ -1014,7 +1050,8 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   } else {
     bool nt = c->span_bytes > tuning().mall_bytes;
     if (tuning().force_nt >= 0) nt = tuning().force_nt != 0;
-    if (nt) hipLaunchKernelGGL((k_tile<T, false, true>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
+    static const int dyn = getenv("QSIM_TILE_DYNLDS") ? atoi(getenv("QSIM_TILE_DYNLDS")) : 0;
+    if (nt) hipLaunchKernelGGL((k_tile<T, false, true>), dim3((unsigned)ntiles), dim3(kTileThreads), dyn, stream, a, (unsigned)ntiles);
     else hipLaunchKernelGGL((k_tile<T, false, false>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
   }
   prof.done(stream);
