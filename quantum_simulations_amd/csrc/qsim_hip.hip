@@ -749,6 +749,9 @@ __device__ __forceinline__ unsigned lds_slot(unsigned t) { return t ^ ((t >> 4) 
 #define QS_IP_FNMA(D, S, V, C) asm volatile("v_fma_f64 %0, -%1, %2, %3" : "+v"(D) : "s"(S), "v"(V), "v"(C))   /* D = -S*V + C */
 #define QS_IP_MOV(D, V)        asm volatile("v_mov_b64 %0, %1" : "+v"(D) : "v"(V))                              /* D = V        */
 #define QS_IP_NEG(D, V)        asm volatile("v_mul_f64 %0, -1.0, %1" : "+v"(D) : "v"(V))                        /* D = -V       */
+#if defined(QSIM_PLAIN_ALL)
+#define QS_D1(A, B) { const double2 a_ = A, b_ = B; A = cfma(u01, b_, cmul(u00, a_)); B = cfma(u11, b_, cmul(u10, a_)); }
+#else
 #define QS_D1(A, B) {                                                                               \
     double t0_ = fma(-u00.y, A.y, u00.x * A.x), t1_ = fma(u00.y, A.x, u00.x * A.y);                 \
     double t2_ = fma(-u10.y, A.y, u10.x * A.x), t3_ = fma(u10.y, A.x, u10.x * A.y);                 \
@@ -756,24 +759,68 @@ __device__ __forceinline__ unsigned lds_slot(unsigned t) { return t ^ ((t >> 4) 
     t2_ = fma(-u11.y, B.y, fma(u11.x, B.x, t2_)); t3_ = fma(u11.x, B.y, t3_);                       \
     QS_IP_FNMA(A.x, u01.y, B.y, t0_); QS_IP_FMA(A.y, u01.y, B.x, t1_);                              \
     QS_IP_FMA(B.y, u11.y, B.x, t3_); QS_IP_MOV(B.x, t2_); }
+#endif
+#if defined(QSIM_PLAIN_ALL)
+#define QS_AN(A, B) { const double2 a_ = A, b_ = B; A = cmul(u01, b_); B = cmul(u10, a_); }
+#else
 #define QS_AN(A, B) {                                                                               \
     const double t2_ = fma(-u10.y, A.y, u10.x * A.x), t3_ = fma(u10.y, A.x, u10.x * A.y);           \
     const double t0_ = u01.x * B.x, t1_ = u01.x * B.y;                                              \
     QS_IP_FNMA(A.x, u01.y, B.y, t0_); QS_IP_FMA(A.y, u01.y, B.x, t1_);                              \
     QS_IP_MOV(B.x, t2_); QS_IP_MOV(B.y, t3_); }
+#endif
+#if defined(QSIM_PLAIN_PERM) || defined(QSIM_PLAIN_ALL)
+#define QS_SW(A, B) { const double2 t_ = A; A = B; B = t_; }
+#else
+#if defined(QSIM_SWAP_MOV)
 #define QS_SW(A, B) { const double t0_ = A.x, t1_ = A.y;                                            \
     QS_IP_MOV(A.x, B.x); QS_IP_MOV(A.y, B.y); QS_IP_MOV(B.x, t0_); QS_IP_MOV(B.y, t1_); }
+#else
+#define QS_SWAP64(P, Q) {                                                                           \
+    unsigned pl_ = __double2loint(P), ph_ = __double2hiint(P), ql_ = __double2loint(Q), qh_ = __double2hiint(Q); \
+    asm volatile("v_swap_b32 %0, %1" : "+v"(pl_), "+v"(ql_));                                       \
+    asm volatile("v_swap_b32 %0, %1" : "+v"(ph_), "+v"(qh_));                                       \
+    P = __hiloint2double(ph_, pl_); Q = __hiloint2double(qh_, ql_); }
+#define QS_SW(A, B) { QS_SWAP64(A.x, B.x) QS_SWAP64(A.y, B.y) }
+#endif
+#endif
+#if defined(QSIM_PLAIN_ALL)
+#define QS_DR(A, B) { const double2 a_ = A, b_ = B;                                               \
+    A = make_double2(fma(u01.x, b_.x, u00.x * a_.x), fma(u01.x, b_.y, u00.x * a_.y));               \
+    B = make_double2(fma(u11.x, b_.x, u10.x * a_.x), fma(u11.x, b_.y, u10.x * a_.y)); }
+#else
 #define QS_DR(A, B) {                                                                               \
     const double tx_ = u00.x * A.x, ty_ = u00.x * A.y, sx_ = u10.x * A.x, sy_ = u10.x * A.y;        \
     QS_IP_FMA(A.x, u01.x, B.x, tx_); QS_IP_FMA(A.y, u01.x, B.y, ty_);                               \
     QS_IP_FMA(B.x, u11.x, B.x, sx_); QS_IP_FMA(B.y, u11.x, B.y, sy_); }
+#endif
+#if defined(QSIM_PLAIN_PERM) || defined(QSIM_PLAIN_ALL)
+#define QS_YL(A, B) { const double2 a_ = A, b_ = B; A = make_double2(b_.y, -b_.x); B = make_double2(-a_.y, a_.x); }
+#else
 #define QS_YL(A, B) { const double t0_ = A.x, t1_ = A.y;                                            \
     QS_IP_MOV(A.x, B.y); QS_IP_NEG(A.y, B.x); QS_IP_NEG(B.x, t1_); QS_IP_MOV(B.y, t0_); }
+#endif
+#if defined(QSIM_PLAIN_ALL)
+#define QS_PH(A) { A = cmul(u00, A); }
+#else
 #define QS_PH(A) { const double p_ = u00.y * A.x, t_ = u00.x * A.x;                                 \
     QS_IP_FNMA(A.x, u00.y, A.y, t_); QS_IP_FMA(A.y, u00.x, A.y, p_); }
+#endif
+#if defined(QSIM_PLAIN_PERM) || defined(QSIM_PLAIN_ALL)
+#define QS_PN(A) { A = make_double2(-A.x, -A.y); }
+#else
 #define QS_PN(A) { QS_IP_NEG(A.x, A.x); QS_IP_NEG(A.y, A.y); }
+#endif
+#if defined(QSIM_PLAIN_PERM) || defined(QSIM_PLAIN_ALL)
+#define QS_PI(A) { A = make_double2(-A.y, A.x); }
+#else
 #define QS_PI(A) { const double t_ = A.x; QS_IP_NEG(A.x, A.y); QS_IP_MOV(A.y, t_); }
+#endif
+#if defined(QSIM_PLAIN_PERM) || defined(QSIM_PLAIN_ALL)
+#define QS_PM(A) { A = make_double2(A.y, -A.x); }
+#else
 #define QS_PM(A) { const double t_ = A.x; QS_IP_MOV(A.x, A.y); QS_IP_NEG(A.y, t_); }
+#endif
 // register pairs (bit J clear / set) of each 1q variant
 #define QS_PAIRS_0(OP) OP(x0, x1) OP(x2, x3) OP(x4, x5) OP(x6, x7)
 #define QS_PAIRS_1(OP) OP(x0, x2) OP(x1, x3) OP(x4, x6) OP(x5, x7)
