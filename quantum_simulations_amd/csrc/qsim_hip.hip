@@ -681,7 +681,7 @@ constexpr int kGroupBits = 3;
 #define QSIM_TILE_THREADS 256
 #endif
 constexpr int kTileThreads = QSIM_TILE_THREADS;
-constexpr int kTileThreadBits = kTileThreads == 128 ? 7 : 8;
+constexpr int kTileThreadBits = kTileThreads == 64 ? 6 : kTileThreads == 128 ? 7 : kTileThreads == 256 ? 8 : kTileThreads == 512 ? 9 : 10;
 constexpr int kTileMaxGates = 144;     // entries incl. group headers  (2304 B of kernel arguments)
 constexpr int kTileMaxMat = 104;       // complex matrix pool          (1664 B)
 
@@ -1097,8 +1097,7 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   } else {
     bool nt = c->span_bytes > tuning().mall_bytes;
     if (tuning().force_nt >= 0) nt = tuning().force_nt != 0;
-    static const int dyn = getenv("QSIM_TILE_DYNLDS") ? atoi(getenv("QSIM_TILE_DYNLDS")) : 0;
-    if (nt) hipLaunchKernelGGL((k_tile<T, false, true>), dim3((unsigned)ntiles), dim3(kTileThreads), dyn, stream, a, (unsigned)ntiles);
+    if (nt) hipLaunchKernelGGL((k_tile<T, false, true>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
     else hipLaunchKernelGGL((k_tile<T, false, false>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
   }
   prof.done(stream);
@@ -1113,6 +1112,7 @@ static int launch_tile_any(const TileArgs& a, int T, const qsim_chunk* c, hipStr
     case 9: return launch_tile<9>(a, c, stream, alg_bytes);
     case 10: return launch_tile<10>(a, c, stream, alg_bytes);
     case 11: return launch_tile<11>(a, c, stream, alg_bytes);
+    case 12: return launch_tile<12>(a, c, stream, alg_bytes);
   }
   return fail(QSIM_ERR_INVALID, "internal: tile size %d", T);
 }

@@ -5,7 +5,11 @@ Mirrors wenbo_engine/runner/single_node.py:78-346.  The 2^n state is ONE HBM all
 structure -- per step: partner groups first (local ops on the group's chunks, then the
 non-local butterflies `apply_1q_pair / apply_2q_pair_* / apply_2q_quad`), then the remaining
 chunks -- runs unchanged, minus everything that existed only because chunks lived on disk
-(double-buffer directories, fsync, manifest, WAL, fencing: SURVEY 2 rows 4-5, out of scope).
+(per-step double-buffer directories, fsync, fencing: SURVEY 2 rows 4-5, out of scope).
+Step-level checkpoint / resume is opt-in: `checkpoint_every=N` downloads the
+state every N steps into `work_dir/state_<a|b>` (the reference's buffer layout, complex128) and
+commits it in `work_dir/wal.json` (the reference's document, quantum_simulations_amd/wal.py); a
+later `run()` on the same directory and circuit resumes after the last committed step.
 
 `run()` returns an `HbmStateBuffer` (the reference returns the path of the committed buffer
 directory); `collect_state()` accepts it and yields the complex128 vector, undoing the staging
@@ -61,9 +65,12 @@ def build_steps(cd: dict, k: int, use_fusion: bool, use_staging: bool, staging_m
 def run(circuit_dict: dict, work_dir: str | Path | None = None, chunk_size: int = 1 << 20,
         kernel: str = "hip", use_wal: bool = True, use_fencing: bool = False,
         use_fusion: bool = False, use_staging: bool = False,
-        staging_method: str = "heuristic", device: int = 0) -> HbmStateBuffer:
-    """Run the full circuit on HBM-resident chunks.  `use_wal` / `use_fencing` are accepted for
-    signature compatibility and ignored (no on-disk buffers to protect)."""
+        staging_method: str = "heuristic", device: int = 0, checkpoint_every: int = 0,
+        checkpoint_dtype: str = "complex128", _stop_after_step: int | None = None) -> HbmStateBuffer:
+    """Run the full circuit on HBM-resident chunks.  `use_fencing` is accepted for signature
+    compatibility and ignored; `use_wal` matters only together with `checkpoint_every > 0` (see
+    the module docstring).  `_stop_after_step` (tests) raises after that step, like the
+    reference's WE_CRASH_AFTER_CHUNK crash injection (single_node.py:61-63)."""
     cd = validate_circuit_dict(circuit_dict)
     n = cd["number_of_qubits"]
     N = 1 << n
@@ -75,13 +82,37 @@ def run(circuit_dict: dict, work_dir: str | Path | None = None, chunk_size: int 
     k = int(math.log2(chunk_size))
     steps, log_to_phys = build_steps(cd, k, use_fusion, use_staging, staging_method)
 
-    state = DeviceChunk.zero_state(n, device)  # |0..0>: chunk 0, element 0 = 1 (block_store.py:35-65)
+    work = Path(work_dir) if work_dir is not None else None
+    log = None
+    first_step = 0
+    if checkpoint_every > 0 and use_wal:
+        if work is None:
+            raise ValueError("checkpoint_every needs a work_dir")
+        from quantum_simulations_amd.storage.block_store import load_to_device, write_state
+        from quantum_simulations_amd.wal import WAL
+        log = WAL(work / "wal.json", circuit_dict=cd)   # raises on a different circuit
+        first_step = min(log.done_steps, len(steps))
+    if first_step > 0:
+        state = load_to_device(work / f"state_{log.committed_buf}", device)
+        if state.k != n:
+            raise ValueError(f"checkpoint holds {state.k} qubits, circuit has {n}")
+    else:
+        state = DeviceChunk.zero_state(n, device)  # |0..0>: chunk 0, element 0 = 1 (block_store.py:35-65)
     n_chunks = N // chunk_size
     chunks = [state.view(c * chunk_size, k) for c in range(n_chunks)] if n_chunks > 1 else [state]
-    for step in steps:
+    for idx in range(first_step, len(steps)):
+        step = steps[idx]
         _apply_step(state, chunks, step["local_ops"], step["nonlocal_ops"], k)
+        if log is not None and ((idx + 1) % checkpoint_every == 0 or idx + 1 == len(steps)):
+            other = "b" if log.committed_buf == "a" else "a"     # never overwrite the committed buffer
+            write_state(work / f"state_{other}", state, chunk_size, dtype=checkpoint_dtype)
+            log.commit_step(idx, other)
+        if _stop_after_step is not None and idx == _stop_after_step:
+            for c in (chunks if n_chunks > 1 else []):
+                c.close()
+            state.close()
+            raise RuntimeError(f"stopped after step {idx} (test crash injection)")
 
-    work = Path(work_dir) if work_dir is not None else None
     if work is not None and log_to_phys and log_to_phys != list(range(n)):
         work.mkdir(parents=True, exist_ok=True)
         with open(work / "qubit_mapping.json", "w") as f:  # single_node.py:129-134

@@ -5,8 +5,9 @@ The reference keeps every state as `<buffer>/chunks/chunk_%06d.bin` (raw complex
 docs/storage_spec.md) and, after staging, `<work_dir>/qubit_mapping.json`
 (runner/single_node.py:129-134).  This build keeps states in HBM; these helpers write a
 finished run in that format, so the reference's own `collect_state(buf_path, ...)` can read a
-GPU result, and read such a directory back into HBM.  (Step-level double buffering, WAL and
-fencing stay out of scope -- SURVEY 2 rows 4-5.)
+GPU result, and read such a directory back into HBM.  Checkpoints of the GPU runner
+(runner/single_node.run(checkpoint_every=...)) use the same layout with `"dtype": "complex128"`
+so a resumed run loses nothing; the reference's complex64 stays the default for exports.
 """
 from __future__ import annotations
 
@@ -18,6 +19,7 @@ from pathlib import Path
 import numpy as np
 
 DTYPE = np.complex64
+DTYPES = {"complex64": np.complex64, "complex128": np.complex128}
 
 
 def chunk_filename(idx: int) -> str:
@@ -34,9 +36,13 @@ def _replace_atomically(path: Path, payload: bytes) -> None:
 
 
 def write_state(directory: str | Path, state, chunk_size: int = 1 << 20,
-                log_to_phys: list[int] | None = None, work_dir: str | Path | None = None) -> Path:
+                log_to_phys: list[int] | None = None, work_dir: str | Path | None = None,
+                dtype: str = "complex64") -> Path:
     """Write `state` (a `DeviceChunk`, an `HbmStateBuffer` or a complex ndarray) as a reference
-    buffer directory.  Amplitudes are rounded to complex64 like every reference chunk file."""
+    buffer directory.  Amplitudes are rounded to complex64 like every reference chunk file unless
+    `dtype="complex128"` (checkpoints)."""
+    if dtype not in DTYPES:
+        raise ValueError(f"unsupported dtype {dtype}")
     if hasattr(state, "state") and hasattr(state, "n_qubits"):       # HbmStateBuffer
         log_to_phys = log_to_phys if log_to_phys is not None else getattr(state, "log_to_phys", None)
         work_dir = work_dir if work_dir is not None else state.work_dir
@@ -57,10 +63,10 @@ def write_state(directory: str | Path, state, chunk_size: int = 1 << 20,
         else:
             part = np.asarray(state[c * chunk_size:(c + 1) * chunk_size])
         name = chunk_filename(c)
-        _replace_atomically(d / "chunks" / name, np.ascontiguousarray(part, dtype=DTYPE).tobytes())
+        _replace_atomically(d / "chunks" / name, np.ascontiguousarray(part, dtype=DTYPES[dtype]).tobytes())
         names.append(name)
     manifest = {"n_qubits": n, "chunk_size": chunk_size, "n_chunks": len(names),
-                "dtype": "complex64", "chunks": names, "created": time.time()}
+                "dtype": dtype, "chunks": names, "created": time.time()}
     _replace_atomically(d / "manifest.json", json.dumps(manifest, indent=2).encode())
     if log_to_phys and list(log_to_phys) != list(range(n)) and work_dir is not None:
         Path(work_dir).mkdir(parents=True, exist_ok=True)
@@ -76,7 +82,7 @@ def read_manifest(directory: str | Path) -> dict:
         raise ValueError(f"chunk_size*n_chunks={m['chunk_size'] * m['n_chunks']} != 2^n_qubits={1 << m['n_qubits']}")
     if len(m["chunks"]) != m["n_chunks"]:
         raise ValueError(f"chunk list length {len(m['chunks'])} != n_chunks {m['n_chunks']}")
-    if m.get("dtype", "complex64") != "complex64":
+    if m.get("dtype", "complex64") not in DTYPES:
         raise ValueError(f"unsupported dtype {m['dtype']}")
     return m
 
@@ -84,7 +90,8 @@ def read_manifest(directory: str | Path) -> dict:
 def read_state(directory: str | Path) -> np.ndarray:
     """A reference buffer directory -> complex128 vector (physical order, as stored)."""
     m = read_manifest(directory)
-    parts = [np.fromfile(str(Path(directory) / "chunks" / name), dtype=DTYPE) for name in m["chunks"]]
+    dt = DTYPES[m.get("dtype", "complex64")]
+    parts = [np.fromfile(str(Path(directory) / "chunks" / name), dtype=dt) for name in m["chunks"]]
     return np.concatenate(parts).astype(np.complex128)
 
 
@@ -93,7 +100,8 @@ def load_to_device(directory: str | Path, device: int = 0):
     from quantum_simulations_amd.kernel.device import DeviceChunk
     m = read_manifest(directory)
     dev = DeviceChunk.empty(m["n_qubits"], device)
+    dt = DTYPES[m.get("dtype", "complex64")]
     for c, name in enumerate(m["chunks"]):
-        part = np.fromfile(str(Path(directory) / "chunks" / name), dtype=DTYPE)
+        part = np.fromfile(str(Path(directory) / "chunks" / name), dtype=dt)
         dev.upload(part.astype(np.complex128), offset=c * m["chunk_size"])
     return dev

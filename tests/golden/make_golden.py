@@ -19,6 +19,9 @@ Fixture groups:
   G5 v1_sql.npz          v1 SQL engine final states (== G2) + row counts
   G6 chunked_c64.npz     single_node.run(chunk_size=2|4) complex64 results
   G7 chunk_files.json    a buffer directory written by the reference block store
+  G8 wal.json            the write-ahead-log documents the reference leaves after a run
+  G9 qiskit_import.json  import_qiskit.qiskit_to_dict on a duck-typed circuit (qiskit itself is
+                         not installed; the reference function only reads attributes)
 """
 from __future__ import annotations
 
@@ -414,7 +417,50 @@ def make_chunk_files():
     return 1
 
 
+# ------------------------------------------------------------------ G8
+def make_wal():
+    """wal.json of finished reference runs (circuit hash, committed buffer, step count)."""
+    cases = {"bell_2q": ref_fixtures.bell_2q(), "ghz_5": ref_fixtures.ghz(5), "qft_4": ref_fixtures.qft(4),
+             "ry_theta": ref_fixtures.ry_theta(), "cr3_encoded": ref_fixtures.cr3_encoded()}
+    doc = {}
+    for name, cd in cases.items():
+        for fusion in (False, True):
+            with tempfile.TemporaryDirectory() as td:
+                ref_runner.run(cd, td, chunk_size=4, use_wal=True, use_fusion=fusion)
+                wal = json.loads((Path(td) / "wal.json").read_text())
+            doc[f"{name}|fusion={int(fusion)}"] = {"circuit": circuit_to_json(cd), "chunk_size": 4,
+                                                   "use_fusion": fusion, "wal": wal}
+    with open(HERE / "wal.json", "w") as f:
+        json.dump(doc, f)
+    return len(doc)
+
+
+# ------------------------------------------------------------------ G9
+def make_qiskit_import():
+    from wenbo_engine.circuit import import_qiskit as ref_imp
+    sys.path.insert(0, str(REPO / "tests"))
+    from fake_qiskit import FakeCircuit
+    program = [("h", [0], []), ("barrier", [0, 1, 2], []), ("cx", [0, 2], []), ("ry", [1], [0.375]),
+               ("swap", [2, 1], []), ("id", [0], []), ("cz", [1, 0], []), ("cy", [2, 0], []),
+               ("s", [1], []), ("t", [2], []), ("x", [0], []), ("y", [1], []), ("z", [2], []),
+               ("measure", [0], []), ("cnot", [1, 2], [])]
+    doc = {"n_qubits": 3, "program": program,
+           "expected": ref_imp.qiskit_to_dict(FakeCircuit(3, program)),
+           "supported_basis": ref_imp.SUPPORTED_BASIS}
+    try:
+        ref_imp.qiskit_to_dict(FakeCircuit(2, [("rz", [0], [0.1])]))
+    except ValueError as e:
+        doc["unsupported_message"] = str(e)
+    with open(HERE / "qiskit_import.json", "w") as f:
+        json.dump(doc, f)
+    return len(program)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":     # add G8/G9 without rewriting G1-G7
+        print("G8 wal cases:", make_wal())
+        print("G9 qiskit import ops:", make_qiskit_import())
+        sys.exit(0)
     print("G1 gate matrices:", make_gate_matrices())
     print("G2 states:", make_states())
     print("G3 kernel cases:", make_kernels())
@@ -422,3 +468,5 @@ if __name__ == "__main__":
     print("G5 v1 SQL cases:", make_v1())
     print("G6 chunked cases:", make_chunked())
     print("G7 chunk-file case:", make_chunk_files())
+    print("G8 wal cases:", make_wal())
+    print("G9 qiskit import ops:", make_qiskit_import())

@@ -144,3 +144,47 @@ def test_swap_global_local_relayout():
         gpu_nonlocal.swap_global_local(chunks, [0], [2])
     with pytest.raises(ValueError):
         gpu_nonlocal.swap_global_local(chunks, [0, 0], [0, 1])
+
+
+# ---- step-level checkpoint / resume ------------------------------------------
+def test_checkpoint_resume_after_injected_stop(tmp_path):
+    """test_recovery_crash.py tests 2-3 on the GPU runner: stop after a step, run again on the same
+    work_dir, get the uninterrupted result (complex128 checkpoints: no precision lost)."""
+    import json
+    from oracle import dense_oracle as orc
+    from quantum_simulations_amd.circuits import random_1q_cx_circuit
+    from quantum_simulations_amd.runner.single_node import collect_state, run
+    from quantum_simulations_amd.wal import WAL
+    cd = random_1q_cx_circuit(10, depth=12, seed=9)
+    want = orc.simulate(cd)
+    for kwargs in ({}, {"use_fusion": True}, {"use_staging": True}):
+        work = tmp_path / ("w_" + "_".join(kwargs) if kwargs else "w_plain")
+        with pytest.raises(RuntimeError, match="stopped after step"):
+            run(cd, work, chunk_size=1 << 7, checkpoint_every=2, _stop_after_step=4, **kwargs)
+        log = WAL(work / "wal.json", circuit_dict=cd)
+        assert log.done_steps == 4                      # steps 0..3 committed, step 4 lost
+        assert (work / f"state_{log.committed_buf}" / "manifest.json").exists()
+        buf = run(cd, work, chunk_size=1 << 7, checkpoint_every=2, **kwargs)
+        got = collect_state(buf, apply_permutation=True, work_dir=work)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12, err_msg=str(kwargs))
+        final = json.loads((work / "wal.json").read_text())
+        assert final["done_steps"] >= 5 and final["circuit_hash"] == log._doc["circuit_hash"]
+        buf.close()
+        # a finished directory is a no-op resume that still returns the final state
+        buf = run(cd, work, chunk_size=1 << 7, checkpoint_every=2, **kwargs)
+        np.testing.assert_allclose(collect_state(buf, apply_permutation=True, work_dir=work), want,
+                                   rtol=0, atol=1e-12)
+        buf.close()
+
+
+def test_checkpoint_every_step_writes_reference_wal(tmp_path):
+    """checkpoint_every=1 leaves exactly the wal.json the reference leaves (G8)."""
+    import json
+    from quantum_simulations_amd.runner.single_node import run
+    from tests.golden_io import circuit_from_json, jdoc
+    for key, g in jdoc("wal.json").items():
+        cd = circuit_from_json(g["circuit"])
+        work = tmp_path / key.replace("|", "_").replace("=", "")
+        buf = run(cd, work, chunk_size=g["chunk_size"], use_fusion=g["use_fusion"], checkpoint_every=1)
+        buf.close()
+        assert json.loads((work / "wal.json").read_text()) == g["wal"], key

@@ -66,3 +66,41 @@ def test_gpu_run_exports_reference_format(tmp_path):
     np.testing.assert_allclose(dev.download(), stored, atol=0)
     dev.close()
     buf.close()
+
+
+# ---- step log (wal.json) and complex128 checkpoints -------------------------------------------
+def test_wal_document_matches_reference(tmp_path):
+    """G8: circuit hash / field layout of the reference's wal.json; committing every step from
+    buffer a reproduces its final document."""
+    from quantum_simulations_amd.wal import WAL, circuit_hash
+    from tests.golden_io import circuit_from_json
+    for key, g in jdoc("wal.json").items():
+        cd = circuit_from_json(g["circuit"])
+        assert circuit_hash(cd) == g["wal"]["circuit_hash"], key
+        path = tmp_path / key.replace("|", "_") / "wal.json"
+        log = WAL(path, circuit_dict=cd)
+        assert (log.committed_buf, log.done_steps) == ("a", 0)
+        for step in range(g["wal"]["done_steps"]):
+            log.commit_step(step, "b" if log.committed_buf == "a" else "a")
+        assert json.loads(path.read_text()) == g["wal"], key
+        again = WAL(path, circuit_dict=cd)                       # re-open = resume point
+        assert (again.committed_buf, again.done_steps) == (g["wal"]["committed_buf"], g["wal"]["done_steps"])
+
+
+def test_wal_rejects_other_circuit(tmp_path):
+    from quantum_simulations_amd.wal import WAL
+    a = {"number_of_qubits": 2, "gates": [{"qubits": [0], "gate": "H"}]}
+    b = {"number_of_qubits": 2, "gates": [{"qubits": [1], "gate": "H"}]}
+    WAL(tmp_path / "wal.json", circuit_dict=a)
+    with pytest.raises(ValueError, match="circuit hash mismatch"):   # test_recovery_crash.py test 5
+        WAL(tmp_path / "wal.json", circuit_dict=b)
+
+
+def test_complex128_buffer_directory_round_trip(tmp_path):
+    rng = np.random.default_rng(5)
+    psi = rng.standard_normal(64) + 1j * rng.standard_normal(64)
+    d = block_store.write_state(tmp_path / "state_b", psi, chunk_size=16, dtype="complex128")
+    assert block_store.read_manifest(d)["dtype"] == "complex128"
+    np.testing.assert_array_equal(block_store.read_state(d), psi)     # lossless
+    with pytest.raises(ValueError, match="unsupported dtype"):
+        block_store.write_state(tmp_path / "x", psi, chunk_size=16, dtype="float32")
