@@ -711,7 +711,7 @@ struct alignas(16) TileGate {   // 16 bytes: one s_load_dwordx4
   uint16_t blk_mask;       // gate: tile bits OUTSIDE the group that must be 1;
                            // group header: s0 | s1 << 4 | s2 << 8 (ascending tile bits)
   uint16_t mat;            // gate: first TileArgs::mat entry of its matrix (0 when it has none)
-  uint16_t pad;
+  uint16_t pad;            // 0: the device reads mat | pad << 16 as one dword
   uint64_t outer_mask;     // absolute index bits outside the tile that must be 1
 };
 
@@ -931,10 +931,14 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
       x4 = lds[lds_slot(tb | b2)];       x5 = lds[lds_slot(tb | b2 | b0)];
       x6 = lds[lds_slot(tb | b2 | b1)];  x7 = lds[lds_slot(tb | b2 | b1 | b0)];
     }
-    for (int q0 = gi; q0 < ge; ++q0) {
-      const int q = __builtin_amdgcn_readfirstlane(q0);
-      const u32x4 g = a.g[q];                         // one s_load_dwordx4
-      const int mq = g.y & 0xFFFF;   // the pool keeps 3 spare entries, so mq .. mq+3 is always readable
+    // The loop below runs on the CU's single scalar unit for every wave (SALU ~ 2x VALU per gate,
+    // r01f ISA audit), so the bookkeeping is kept to: one add + one 128-bit load for the
+    // descriptor (unsigned index), and the lane predicate evaluated only for gates that have one.
+    for (unsigned q0 = (unsigned)gi, qe = (unsigned)ge; q0 != qe; ++q0) {
+      const unsigned q = __builtin_amdgcn_readfirstlane(q0);
+      const u32x4 g = a.g[q & 0xFF];                  // one s_load_dwordx4 (index the kernarg arrays directly:
+                                                      // a pointer formed into them turns the loads into vector loads)
+      const int mq = g.y & 0xFFFF;                    // (known-small indices fold into the load's offset); pool keeps 3 spare entries
       const double2 u00 = a.mat[mq], u01 = a.mat[mq + 1], u10 = a.mat[mq + 2], u11 = a.mat[mq + 3];
       const u64 outer = (u64)g.z | ((u64)g.w << 32);
       if ((base & outer) != outer) continue;
@@ -942,11 +946,15 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
       // narrowed by hand: a compiler-managed divergent region makes StructurizeCFG rewrite the
       // (uniform) opcode switch into flow blocks whose PHIs double-buffer x0..x7 (see QS_IP_*).
       // Everything up to the restore is VALU on x0..x7 / case-local temporaries + scalar branches.
+      // (Threads that are not `live` -- tiles smaller than 8 x blockDim -- compute on registers
+      // they never write back.)
       const unsigned bm = g.x >> 16;
-      const u64 act = __builtin_amdgcn_ballot_w64(live && (tb & bm) == bm);
-      if (act == 0) continue;
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_mov_b64 exec, %0" : : "s"(act) : "memory");
+      if (bm) {
+        const u64 act = __builtin_amdgcn_ballot_w64((tb & bm) == bm);
+        if (act == 0) continue;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_mov_b64 exec, %0" : : "s"(act) : "memory");
+      }
       __builtin_amdgcn_sched_barrier(0);
       switch (g.x & 0xFF) {
         QS_CASES_1Q(OPC_DENSE1, QS_D1)
