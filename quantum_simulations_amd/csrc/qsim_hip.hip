@@ -319,6 +319,7 @@ struct Tuning {
   int items = 0;      // 0 auto
   int max_gates_per_pass = 128;
   int tile_special = 1;      // real / Y-like / -1 / +-i special-case opcodes in fused passes
+  int tile_merge_diag = 1;   // merge phase gates that share their predicate (OPC_DIAGR)
   int debug_skip_gates = 0;  // QSIM_DEBUG_SKIP_GATES=1: tile passes move data but apply nothing (WRONG results)
   int debug_stats = 0;       // QSIM_DEBUG_STATS=1: print gates / groups per pass to stderr
   int tile_persistent = 0;   // resident grid + next-tile prefetch
@@ -341,6 +342,7 @@ struct Tuning {
     if (const char* e = getenv("QSIM_ITEMS")) items = atoi(e);
     if (const char* e = getenv("QSIM_PASS_GATES")) max_gates_per_pass = std::max(1, atoi(e));
     if (const char* e = getenv("QSIM_TILE_SPECIAL")) tile_special = atoi(e);
+    if (const char* e = getenv("QSIM_TILE_MERGE_DIAG")) tile_merge_diag = atoi(e);
     if (const char* e = getenv("QSIM_DEBUG_SKIP_GATES")) debug_skip_gates = atoi(e);
   }
 };
@@ -697,6 +699,9 @@ enum : uint8_t {
   OPC_PHASE_NEG = 63, // +mask: x = -x                      Z, CZ             (pool: 0)
   OPC_PHASE_I = 71,   // +mask: x = i x                     S                 (pool: 0)
   OPC_PHASE_NI = 79,  // +mask: x = -i x                                      (pool: 0)
+  OPC_DIAGR = 87,     // +{0: bits 0,1; 1: bits 0,2; 2: bits 1,2; 3: bits 0,1,2}: several phase gates
+                      // that share their predicate, one per register bit, merged by the host:
+                      // x_i *= prod of the listed bits' phases that are set in i   (pool: 2 or 3)
   OPC_GROUP = 0xFE    // group header
 };
 // 1q variant: 0..2 = target register bit J, no register control; 3 + 2*J + k = control on the
@@ -821,6 +826,13 @@ __device__ __forceinline__ unsigned lds_slot(unsigned t) { return t ^ ((t >> 4) 
 #else
 #define QS_PM(A) { const double t_ = A.x; QS_IP_MOV(A.x, A.y); QS_IP_NEG(A.y, t_); }
 #endif
+// A *= W with W in vector registers (a product of two pool entries)
+#define QS_IP_FMA_V(D, S, V, C)  asm volatile("v_fma_f64 %0, %1, %2, %3" : "+v"(D) : "v"(S), "v"(V), "v"(C))
+#define QS_IP_FNMA_V(D, S, V, C) asm volatile("v_fma_f64 %0, -%1, %2, %3" : "+v"(D) : "v"(S), "v"(V), "v"(C))
+#define QS_PHS(A, U) { const double p_ = U.y * A.x, t_ = U.x * A.x;                                  \
+    QS_IP_FNMA(A.x, U.y, A.y, t_); QS_IP_FMA(A.y, U.x, A.y, p_); }
+#define QS_PHV(A, W) { const double p_ = W.y * A.x, t_ = W.x * A.x;                                  \
+    QS_IP_FNMA_V(A.x, W.y, A.y, t_); QS_IP_FMA_V(A.y, W.x, A.y, p_); }
 // register pairs (bit J clear / set) of each 1q variant
 #define QS_PAIRS_0(OP) OP(x0, x1) OP(x2, x3) OP(x4, x5) OP(x6, x7)
 #define QS_PAIRS_1(OP) OP(x0, x2) OP(x1, x3) OP(x4, x6) OP(x5, x7)
@@ -966,6 +978,16 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
         QS_CASES_PHASE(OPC_PHASE_NEG, QS_PN)
         QS_CASES_PHASE(OPC_PHASE_I, QS_PI)
         QS_CASES_PHASE(OPC_PHASE_NI, QS_PM)
+        case OPC_DIAGR + 0: { const double2 w_ = cmul(u00, u01);     // bits 0 (u00) and 1 (u01)
+          QS_PHS(x1, u00) QS_PHS(x5, u00) QS_PHS(x2, u01) QS_PHS(x6, u01) QS_PHV(x3, w_) QS_PHV(x7, w_) } break;
+        case OPC_DIAGR + 1: { const double2 w_ = cmul(u00, u01);     // bits 0 (u00) and 2 (u01)
+          QS_PHS(x1, u00) QS_PHS(x3, u00) QS_PHS(x4, u01) QS_PHS(x6, u01) QS_PHV(x5, w_) QS_PHV(x7, w_) } break;
+        case OPC_DIAGR + 2: { const double2 w_ = cmul(u00, u01);     // bits 1 (u00) and 2 (u01)
+          QS_PHS(x2, u00) QS_PHS(x3, u00) QS_PHS(x4, u01) QS_PHS(x5, u01) QS_PHV(x6, w_) QS_PHV(x7, w_) } break;
+        case OPC_DIAGR + 3: {                                        // bits 0 (u00), 1 (u01), 2 (u10)
+          const double2 w01_ = cmul(u00, u01), w02_ = cmul(u00, u10), w12_ = cmul(u01, u10), w012_ = cmul(w01_, u10);
+          QS_PHS(x1, u00) QS_PHS(x2, u01) QS_PHS(x4, u10) QS_PHV(x3, w01_) QS_PHV(x5, w02_) QS_PHV(x6, w12_)
+          QS_PHV(x7, w012_) } break;
         case OPC_DENSE2 + 1: QS_D2(x0, x2, x1, x3) QS_D2(x4, x6, x5, x7) break;   // qa = bit 0, qb = bit 1
         case OPC_DENSE2 + 2: QS_D2(x0, x4, x1, x5) QS_D2(x2, x6, x3, x7) break;   // qa = bit 0, qb = bit 2
         case OPC_DENSE2 + 3: QS_D2(x0, x1, x2, x3) QS_D2(x4, x5, x6, x7) break;   // qa = bit 1, qb = bit 0
@@ -1198,9 +1220,40 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
     TileGate hd;
     std::memset(&hd, 0, sizeof hd);
     hd.opcode = OPC_GROUP;
-    hd.count = (uint8_t)grp.size();
     hd.blk_mask = (uint16_t)(S[0] | (S[1] << 4) | (S[2] << 8));
-    put_gate(a, a->ngates++, hd);
+    const int hd_at = a->ngates++;
+    int n_emitted = 0;
+    auto emit = [&](TileGate g, const double2* m, int nm) {
+      if (nm) {
+        g.mat = (uint16_t)pool;
+        for (int e = 0; e < nm; ++e) a->mat[pool + e] = m[e];
+        pool += nm;
+      }
+      put_gate(a, a->ngates++, g);
+      ++n_emitted;
+    };
+    // Phase gates with ONE register bit and the same predicate (lane bits + outer bits) are merged
+    // (the QFT's CR(k, a), CR(k, b), CR(k, c) for the group's register bits a, b, c): diagonal
+    // gates commute with everything except a non-diagonal gate on one of their bits, so an open
+    // accumulator is written out before such a gate on a register bit it has touched, or at the
+    // end of the group.  One descriptor instead of up to three: the gate loop is scalar-issue bound.
+    struct Acc { uint16_t blk; u64 outer; double2 phi[3]; unsigned touched; int count; TileGate single; };
+    std::vector<Acc> open;
+    auto flush = [&](size_t i) {
+      const Acc acc = open[i];
+      open.erase(open.begin() + (long)i);
+      if (acc.count == 1) { emit(acc.single, &acc.phi[__builtin_ctz(acc.touched)], 1); return; }
+      TileGate g;
+      std::memset(&g, 0, sizeof g);
+      g.blk_mask = acc.blk;
+      g.outer_mask = acc.outer;
+      double2 m[3];
+      int nm = 0;
+      for (int r = 0; r < 3; ++r) if (acc.touched & (1u << r)) m[nm++] = acc.phi[r];
+      if (nm == 1) g.opcode = (uint8_t)(OPC_PHASE + acc.touched);
+      else g.opcode = (uint8_t)(OPC_DIAGR + (acc.touched == 3 ? 0 : acc.touched == 5 ? 1 : acc.touched == 6 ? 2 : 3));
+      emit(g, m, nm);
+    };
     for (size_t mi : grp) {
       const FusedOp& o = ops[members[mi]];
       TileGate g;
@@ -1216,10 +1269,30 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
       };
       auto is = [&](int e, double re, double im) { return o.m[e].x == re && o.m[e].y == im; };
       const bool sp = tuning().tile_special;
+      done[mi] = 1;
+      (*emitted)[mi] = 1;
+      --left;
       if (o.kind == TG_PHASE) {
         for (int t = 0; t < o.nbits; ++t) require_one(o.bits[t]);
         const int fam = !sp ? OPC_PHASE : (is(0, -1, 0) ? OPC_PHASE_NEG : (is(0, 0, 1) ? OPC_PHASE_I : (is(0, 0, -1) ? OPC_PHASE_NI : OPC_PHASE)));
         g.opcode = (uint8_t)(fam + reg_mask);
+        if (tuning().tile_merge_diag && fam == OPC_PHASE && __builtin_popcount(reg_mask) == 1) {
+          const int r = __builtin_ctz(reg_mask);
+          size_t i = 0;
+          while (i < open.size() && !(open[i].blk == g.blk_mask && open[i].outer == g.outer_mask)) ++i;
+          if (i == open.size()) {
+            Acc acc;
+            acc.blk = g.blk_mask; acc.outer = g.outer_mask; acc.touched = 0; acc.count = 0; acc.single = g;
+            for (int e = 0; e < 3; ++e) acc.phi[e] = make_double2(1.0, 0.0);
+            open.push_back(acc);
+          }
+          Acc& acc = open[i];
+          const double2 f = acc.phi[r], m = o.m[0];
+          acc.phi[r] = make_double2(f.x * m.x - f.y * m.y, f.x * m.y + f.y * m.x);
+          acc.touched |= 1u << r;
+          ++acc.count;
+          continue;
+        }
       } else if (o.kind == TG_DENSE2) {
         g.opcode = (uint8_t)(OPC_DENSE2 + 3 * reg_pos(tile_pos(o.target[0])) + reg_pos(tile_pos(o.target[1])));
       } else {
@@ -1230,17 +1303,16 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
         if (sp && o.kind == TG_ANTI1 && is(1, 0, -1) && is(2, 0, 1)) fam = OPC_YLIKE1;
         g.opcode = (uint8_t)(fam + opc_1q_variant(J, ctrl_reg));
       }
-      const int need = pool_entries(o);
-      if (need) {
-        g.mat = (uint16_t)pool;
-        for (int e = 0; e < o.nm && e < need; ++e) a->mat[pool + e] = o.m[e];
-        pool += need;
+      if (o.kind != TG_PHASE) {               // a non-diagonal gate: its targets end the open phase runs on them
+        unsigned tmask = 0;
+        for (int t = 0; t < o.ntargets; ++t) tmask |= 1u << reg_pos(tile_pos(o.target[t]));
+        for (size_t i = open.size(); i-- > 0;) if (open[i].touched & tmask) flush(i);
       }
-      put_gate(a, a->ngates++, g);
-      done[mi] = 1;
-      (*emitted)[mi] = 1;
-      --left;
+      emit(g, o.m, std::min(pool_entries(o), o.nm));
     }
+    while (!open.empty()) flush(0);
+    hd.count = (uint8_t)n_emitted;
+    put_gate(a, hd_at, hd);
   }
 }
 

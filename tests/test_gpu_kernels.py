@@ -458,3 +458,39 @@ def test_streaming_cache_policy_on_small_states():
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "STREAMING-POLICY-OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("n", [9, 12, 15])
+def test_fused_phase_runs_keep_their_order(hip, n):
+    """Phase gates that share a predicate are merged per register group (OPC_DIAGR) and written out
+    late; a non-diagonal gate on one of their bits must still see them in list order.  Dense in
+    phase gates (T, R, CR with few distinct controls) interleaved with H / RY / CNOT on the same
+    qubits, against the oracle."""
+    for seed in range(4):
+        rng = np.random.default_rng(4000 + 10 * n + seed)
+        ctrls = [int(q) for q in rng.choice(n, size=3, replace=False)]
+        ops = []
+        for _ in range(160):
+            r = rng.random()
+            q = int(rng.integers(n))
+            if r < 0.45:
+                c = ctrls[int(rng.integers(3))]
+                if c == q:
+                    continue
+                pair = [c, q] if rng.random() < 0.5 else [q, c]
+                ops.append((pair, orc.gate_matrix("CR", {"k": int(rng.integers(1, 7))})))
+            elif r < 0.65:
+                ops.append(([q], orc.gate_matrix(("T", "R", "S", "Z")[int(rng.integers(4))], {"k": int(rng.integers(1, 7))})))
+            elif r < 0.85:
+                ops.append(([q], orc.gate_matrix(("H", "RY", "X")[int(rng.integers(3))], {"theta": float(rng.uniform(0, 6))})))
+            else:
+                t = int(rng.integers(n))
+                if t != q:
+                    ops.append(([q, t], orc.gate_matrix("CNOT")))
+        psi0 = _rand_state(n, 900 + seed)
+        want = psi0.copy()
+        orc.apply_ops(want, ops)
+        dev = hip.DeviceChunk.from_numpy(psi0)
+        dev.apply_ops(ops, fused=True)
+        np.testing.assert_allclose(dev.download(), want, rtol=0, atol=1e-11, err_msg=f"n={n} seed={seed}")
+        dev.close()
