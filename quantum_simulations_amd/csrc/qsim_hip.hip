@@ -1187,26 +1187,32 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
     std::vector<int> S;               // tile bits of this group
     std::vector<size_t> grp;          // indices into members
     u64 blocked = 0;
-    int pool_need = 0;
+    // Budget estimate in half units: a phase gate that may be merged with others (OPC_DIAGR) is
+    // counted as half a descriptor and half a pool entry; the exact budget is enforced when the
+    // group is written out (a group that overflows is cut there, the rest waits for the next pass).
+    int slots2 = 0, pool2 = 0;
+    const bool merge_on = tuning().tile_merge_diag != 0;
     for (size_t mi = 0; mi < members.size(); ++mi) {
       if (done[mi]) continue;
       const FusedOp& o = ops[members[mi]];
       const u64 qm = op_qmask(o);
       bool ok = !(blocked & qm);
       int need[2], nneed = 0;
+      const bool mergeable = merge_on && o.kind == TG_PHASE && pool_entries(o) == 1;
       if (ok) {
         for (int t = 0; t < o.ntargets; ++t) {
           const int p = tile_pos(o.target[t]);
           if (std::find(S.begin(), S.end(), p) == S.end()) need[nneed++] = p;
         }
         if ((int)S.size() + nneed > kGroupBits) ok = false;
-        if (a->ngates + 1 + (int)grp.size() + 1 > kTileMaxGates || (int)grp.size() + 1 > 255) ok = false;
-        if (pool + pool_need + pool_entries(o) > kTileMaxMat - 3) ok = false;
+        if (2 * (a->ngates + 1) + slots2 + (mergeable ? 1 : 2) > 2 * kTileMaxGates || (int)grp.size() + 1 > 255) ok = false;
+        if (2 * pool + pool2 + (mergeable ? 1 : 2 * pool_entries(o)) > 2 * (kTileMaxMat - 3)) ok = false;
       }
       if (!ok) { blocked |= qm; continue; }
       for (int t = 0; t < nneed; ++t) S.push_back(need[t]);
       grp.push_back(mi);
-      pool_need += pool_entries(o);
+      slots2 += mergeable ? 1 : 2;
+      pool2 += mergeable ? 1 : 2 * pool_entries(o);
     }
     if (grp.empty()) break;           // argument budget exhausted: the rest waits for the next launch
     // pad the group with the highest unused tile bits (high bits keep LDS accesses contiguous)
@@ -1239,6 +1245,7 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
     // end of the group.  One descriptor instead of up to three: the gate loop is scalar-issue bound.
     struct Acc { uint16_t blk; u64 outer; double2 phi[3]; unsigned touched; int count; TileGate single; };
     std::vector<Acc> open;
+    bool cut = false;
     auto flush = [&](size_t i) {
       const Acc acc = open[i];
       open.erase(open.begin() + (long)i);
@@ -1269,6 +1276,12 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
       };
       auto is = [&](int e, double re, double im) { return o.m[e].x == re && o.m[e].y == im; };
       const bool sp = tuning().tile_special;
+      {   // exact budget: descriptors and pool entries written so far + what the open runs will need
+        int reserve_pool = 0;
+        for (const Acc& acc : open) reserve_pool += __builtin_popcount(acc.touched);
+        if (a->ngates + (int)open.size() + 1 > kTileMaxGates ||
+            pool + reserve_pool + std::max(1, pool_entries(o)) > kTileMaxMat - 3) { cut = true; break; }
+      }
       done[mi] = 1;
       (*emitted)[mi] = 1;
       --left;
@@ -1313,6 +1326,7 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
     while (!open.empty()) flush(0);
     hd.count = (uint8_t)n_emitted;
     put_gate(a, hd_at, hd);
+    if (cut) break;                   // argument budget exhausted inside the group
   }
 }
 
