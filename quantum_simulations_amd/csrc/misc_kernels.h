@@ -1,0 +1,195 @@
+// misc_kernels.h -- argument checks and the non-gate kernels (fill, norm, pack, closed-form checkers).
+// Part of the single translation unit qsim_hip.hip (included there, in order; not a standalone header).
+// ------------------------------------------------------------------ argument checks
+static int check_chunk(const qsim_chunk* c, const char* what) {
+  if (!c || !c->amp) return fail(QSIM_ERR_INVALID, "%s: null chunk", what);
+  return QSIM_OK;
+}
+
+static int check_local_qubit(const qsim_chunk* c, int q) {
+  if (q < 0) return fail(QSIM_ERR_INVALID, "qubit %d is negative", q);
+  if (q >= c->k)
+    return fail(QSIM_ERR_NONLOCAL,
+                "qubit %d >= log2(chunk_size)=%d: non-local gate requires layout/collect step",
+                q, c->k);
+  return QSIM_OK;
+}
+
+static int check_group(qsim_chunk* const* cs, int n, const char* what) {
+  for (int i = 0; i < n; ++i) {
+    int rc = check_chunk(cs[i], what);
+    if (rc) return rc;
+    if (cs[i]->k != cs[0]->k) return fail(QSIM_ERR_INVALID, "%s: chunks differ in size", what);
+    if (cs[i]->device != cs[0]->device)
+      return fail(QSIM_ERR_INVALID, "%s: chunks live on different devices", what);
+    for (int j = 0; j < i; ++j)
+      if (cs[i]->amp == cs[j]->amp) return fail(QSIM_ERR_INVALID, "%s: the same chunk twice", what);
+  }
+  return QSIM_OK;
+}
+
+// ------------------------------------------------------------------ misc kernels
+__global__ void k_fill_zero(double2* p, u64 n, int set0) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    p[i] = make_double2((i == 0 && set0) ? 1.0 : 0.0, 0.0);
+}
+
+__device__ __forceinline__ u64 splitmix64(u64 x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// amplitude i = (u(2i), u(2i+1)), u(j) = (splitmix64(seed + j) >> 11) * 2^-52 - 1 in [-1, 1)
+__global__ void k_fill_random(double2* p, u64 n, u64 seed) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double re = (double)(splitmix64(seed + 2 * i) >> 11) * (1.0 / 4503599627370496.0) - 1.0;
+    const double im = (double)(splitmix64(seed + 2 * i + 1) >> 11) * (1.0 / 4503599627370496.0) - 1.0;
+    p[i] = make_double2(re, im);
+  }
+}
+
+__global__ void k_scale(double2* p, u64 n, double s) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double2 v = p[i];
+    p[i] = make_double2(v.x * s, v.y * s);
+  }
+}
+
+__global__ void k_copy(double2* __restrict__ dst, const double2* __restrict__ src, u64 n) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+// dst[j] = src[insert(j, bit, value)]  /  inverse
+__global__ void k_pack_half(double2* __restrict__ dst, const double2* __restrict__ src, u64 n_half,
+                            int bit, u64 value_off) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n_half; j += stride) {
+    const u64 i = (((j >> bit) << (bit + 1)) | (j & ((1ull << bit) - 1))) | value_off;
+    dst[j] = src[i];
+  }
+}
+__global__ void k_unpack_half(double2* __restrict__ dst, const double2* __restrict__ src, u64 n_half,
+                              int bit, u64 value_off) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n_half; j += stride) {
+    const u64 i = (((j >> bit) << (bit + 1)) | (j & ((1ull << bit) - 1))) | value_off;
+    dst[i] = src[j];
+  }
+}
+
+// slab gather / scatter for the all-to-all re-layout: j runs over the 2^(k-m) amplitudes whose
+// bits `pos` equal the pattern folded into value_off
+__global__ void k_pack_bits(double2* __restrict__ dst, const double2* __restrict__ src, u64 n_slab,
+                            int npos, int p0, int p1, int p2, u64 value_off) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n_slab; j += stride)
+    dst[j] = ld_amp<true>(src + (expand_index(j, npos, p0, p1, p2) | value_off));
+}
+__global__ void k_unpack_bits(double2* __restrict__ dst, const double2* __restrict__ src, u64 n_slab,
+                              int npos, int p0, int p1, int p2, u64 value_off) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n_slab; j += stride)
+    dst[expand_index(j, npos, p0, p1, p2) | value_off] = ld_amp<true>(src + j);
+}
+
+// exchange slab (bits pos == a_off pattern) of chunk A with slab (bits pos == b_off pattern) of chunk B
+__global__ void k_swap_slabs(double2* __restrict__ a, double2* __restrict__ b, u64 n_slab,
+                             int npos, int p0, int p1, int p2, u64 a_off, u64 b_off) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n_slab; j += stride) {
+    const u64 e = expand_index(j, npos, p0, p1, p2);
+    const double2 x = a[e | a_off], y = b[e | b_off];
+    a[e | a_off] = y;
+    b[e | b_off] = x;
+  }
+}
+
+constexpr int kReduceBlocks = 2048;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+template <bool MAX>
+__device__ __forceinline__ void block_reduce_store(double v, double* out) {
+  __shared__ double part[kBlock / 64];
+  v = MAX ? wave_max(v) : wave_sum(v);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = part[0];
+    for (int w = 1; w < kBlock / 64; ++w) r = MAX ? fmax(r, part[w]) : r + part[w];
+    out[blockIdx.x] = r;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_norm2_partial(const double2* p, u64 n, double* partial) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double2 v = p[i];
+    acc = fma(v.x, v.x, fma(v.y, v.y, acc));
+  }
+  block_reduce_store<false>(acc, partial);
+}
+
+// kind 0: GHZ, kind 1: GHZ+QFT closed form.  `base` = global index of amp 0.
+struct BitPerm { unsigned char to_logical[64]; int active; };   // physical index bit -> logical qubit
+
+__global__ __launch_bounds__(kBlock) void k_closed_form_err(const double2* p, u64 n, int kind,
+                                                            int n_total, u64 base, double* partial,
+                                                            const BitPerm perm) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  const double inv_n = exp2(-(double)n_total);
+  const double amp = exp2(-0.5 * (double)(n_total + 1));
+  const u64 last = (n_total >= 64) ? ~0ull : ((1ull << n_total) - 1);
+  double worst = 0.0;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    u64 y = base + i;
+    if (perm.active) {                       // staged layout: logical index from the physical one
+      const u64 x = y;
+      y = 0;
+      for (int b = 0; b < n_total; ++b) y |= ((x >> b) & 1ull) << perm.to_logical[b];
+    }
+    double er, ei;
+    if (kind == 0) {
+      er = (y == 0 || y == last) ? 0.70710678118654752440 : 0.0;
+      ei = 0.0;
+    } else {
+      // exp(-2 pi i y / 2^n): y * 2^-n is exact in double for n <= 52
+      double s, c;
+      sincospi(-2.0 * ((double)y * inv_n), &s, &c);
+      er = amp * (1.0 + c);
+      ei = amp * s;
+    }
+    const double2 v = p[i];
+    worst = fmax(worst, hypot(v.x - er, v.y - ei));
+  }
+  block_reduce_store<true>(worst, partial);
+}
+
+static int ensure_scratch(qsim_chunk* c) {
+  if (!c->scratch) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc((void**)&c->scratch, sizeof(double) * kReduceBlocks));
+  }
+  return QSIM_OK;
+}
+
+static unsigned stream_grid(u64 n) {
+  const u64 want = (n + kBlock - 1) / kBlock;
+  return (unsigned)std::min<u64>(std::max<u64>(want, 1), 8192);
+}

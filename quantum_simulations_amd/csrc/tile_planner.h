@@ -1,0 +1,380 @@
+// tile_planner.h -- host planner of the fused passes: op list -> passes -> register groups.
+// Part of the single translation unit qsim_hip.hip (included there, in order; not a standalone header).
+// ---- host planner: op list -> passes -> register groups ----------------------------------------
+enum { TG_DENSE1 = 0, TG_PHASE = 1, TG_DENSE2 = 2, TG_ANTI1 = 3, TG_SWAP1 = 4 };   // FusedOp::kind
+
+struct FusedOp {
+  int kind;            // TG_DENSE1 / TG_ANTI1 / TG_SWAP1 (target, optional control), TG_PHASE, TG_DENSE2
+  int target[2];       // 1q kinds: target[0]; TG_DENSE2: (qa, qb)
+  int ntargets;
+  int control;         // 1q kinds: control qubit or -1
+  int bits[2];         // TG_PHASE: qubits that must be 1
+  int nbits;
+  int qubits[2];       // every qubit the op touches (for ordering)
+  int nq;
+  double2 m[16];
+  int nm;              // matrix entries (4, 1 or 16)
+  int halvings;        // algorithmic bytes = 32 B x 2^(k - halvings)  
+};
+
+static void set_1q_kind(FusedOp* o) {   // o->m holds the 2x2
+  const bool zero_diag = o->m[0].x == 0 && o->m[0].y == 0 && o->m[3].x == 0 && o->m[3].y == 0;
+  const bool ones = o->m[1].x == 1 && o->m[1].y == 0 && o->m[2].x == 1 && o->m[2].y == 0;
+  o->kind = zero_diag ? (ones ? TG_SWAP1 : TG_ANTI1) : TG_DENSE1;
+}
+
+// Same classification as gate_1q / gate_2q; returns false for an identity.
+static bool classify_op(int nq, const int32_t* q, const double* U, FusedOp* o) {
+  o->nq = nq;
+  o->qubits[0] = q[0];
+  o->qubits[1] = nq == 2 ? q[1] : -1;
+  o->control = -1;
+  o->nbits = 0;
+  o->ntargets = 0;
+  o->halvings = 0;
+  auto C = [&](int i) { return make_double2(U[2 * i], U[2 * i + 1]); };
+  if (nq == 1) {
+    const bool diag = is_zero(U[2], U[3]) && is_zero(U[4], U[5]);
+    if (diag && is_one(U[0], U[1])) {
+      if (is_one(U[6], U[7])) return false;
+      o->kind = TG_PHASE; o->bits[0] = q[0]; o->nbits = 1; o->m[0] = C(3); o->nm = 1;
+      return true;
+    }
+    o->target[0] = q[0]; o->ntargets = 1;
+    for (int i = 0; i < 4; ++i) o->m[i] = C(i);
+    o->nm = 4;
+    set_1q_kind(o);
+    return true;
+  }
+  auto z = [&](int r, int c) { return is_zero(U[2 * (4 * r + c)], U[2 * (4 * r + c) + 1]); };
+  auto one = [&](int r, int c) { return is_one(U[2 * (4 * r + c)], U[2 * (4 * r + c) + 1]); };
+  bool offdiag_zero = true;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c)
+      if (r != c && !z(r, c)) offdiag_zero = false;
+  const bool ctrl_a = one(0, 0) && one(1, 1) && z(0, 1) && z(1, 0) && z(0, 2) && z(0, 3) && z(1, 2) &&
+                      z(1, 3) && z(2, 0) && z(2, 1) && z(3, 0) && z(3, 1);
+  const bool ctrl_b = one(0, 0) && one(2, 2) && z(0, 2) && z(2, 0) && z(0, 1) && z(0, 3) && z(2, 1) &&
+                      z(2, 3) && z(1, 0) && z(1, 2) && z(3, 0) && z(3, 2);
+  if (offdiag_zero && one(0, 0) && one(1, 1) && one(2, 2)) {
+    if (one(3, 3)) return false;
+    o->kind = TG_PHASE; o->bits[0] = q[0]; o->bits[1] = q[1]; o->nbits = 2; o->m[0] = C(15); o->nm = 1;
+    return true;
+  }
+  if (ctrl_a || ctrl_b) {
+    o->control = ctrl_a ? q[0] : q[1];
+    o->target[0] = ctrl_a ? q[1] : q[0];
+    o->ntargets = 1;
+    if (ctrl_a) { o->m[0] = C(10); o->m[1] = C(11); o->m[2] = C(14); o->m[3] = C(15); }
+    else        { o->m[0] = C(5);  o->m[1] = C(7);  o->m[2] = C(13); o->m[3] = C(15); }
+    o->nm = 4;
+    set_1q_kind(o);
+    if (o->kind == TG_DENSE1 && o->m[1].x == 0 && o->m[1].y == 0 && o->m[2].x == 0 && o->m[2].y == 0 &&
+        o->m[0].x == 1 && o->m[0].y == 0) {   // controlled phase written as CU: diag(1, d)
+      o->kind = TG_PHASE; o->bits[0] = q[0]; o->bits[1] = q[1]; o->nbits = 2; o->m[0] = o->m[3]; o->nm = 1;
+      o->ntargets = 0; o->control = -1;
+    }
+    return true;
+  }
+  o->kind = TG_DENSE2; o->target[0] = q[0]; o->target[1] = q[1]; o->ntargets = 2;
+  for (int i = 0; i < 16; ++i) o->m[i] = C(i);
+  o->nm = 16;
+  const bool swap = one(0, 0) && one(3, 3) && one(1, 2) && one(2, 1) && z(1, 1) && z(2, 2) && z(0, 1) && z(0, 2) &&
+                    z(0, 3) && z(1, 0) && z(1, 3) && z(2, 0) && z(2, 3) && z(3, 0) && z(3, 1) && z(3, 2);
+  o->halvings = swap ? 1 : 0;   // SWAP only exchanges |01> and |10>
+  return true;
+}
+
+template <int T>
+static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t stream, double alg_bytes) {
+  if constexpr (T > kTileBitsMax) {
+    return fail(QSIM_ERR_INVALID, "internal: tile size %d not built", T);
+  } else {
+  const u64 ntiles = 1ull << (c->k - T);
+  ProfileScope prof(6, alg_bytes, stream, 32.0 * (double)amps(c));
+  if (tuning().tile_persistent) {
+    static int resident = 0;            // workgroups per CU that registers and LDS admit
+    if (!resident) {
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile<T, true, true>, kTileThreads, 0) != hipSuccess || n < 1) n = 1;
+      resident = n;
+    }
+    const int per_cu = std::max(1, std::min(tuning().tile_wgs_per_cu, resident));
+    const u64 blocks = std::min<u64>(ntiles, (u64)tuning().num_cus * per_cu);
+    hipLaunchKernelGGL((k_tile<T, true, true>), dim3((unsigned)blocks), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
+  } else {
+    bool nt = c->span_bytes > tuning().mall_bytes;
+    if (tuning().force_nt >= 0) nt = tuning().force_nt != 0;
+    if (nt) hipLaunchKernelGGL((k_tile<T, false, true>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
+    else hipLaunchKernelGGL((k_tile<T, false, false>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
+  }
+  prof.done(stream);
+  HIP_TRY(hipGetLastError());
+  return QSIM_OK;
+  }
+}
+
+static int launch_tile_any(const TileArgs& a, int T, const qsim_chunk* c, hipStream_t stream, double alg_bytes) {
+  switch (T) {
+    case 8: return launch_tile<8>(a, c, stream, alg_bytes);
+    case 9: return launch_tile<9>(a, c, stream, alg_bytes);
+    case 10: return launch_tile<10>(a, c, stream, alg_bytes);
+    case 11: return launch_tile<11>(a, c, stream, alg_bytes);
+    case 12: return launch_tile<12>(a, c, stream, alg_bytes);
+  }
+  return fail(QSIM_ERR_INVALID, "internal: tile size %d", T);
+}
+
+constexpr int kTileMinChunk = 8;   // smaller chunks run gate by gate
+
+static inline u64 op_qmask(const FusedOp& o) {
+  u64 m = 1ull << o.qubits[0];
+  if (o.nq == 2) m |= 1ull << o.qubits[1];
+  return m;
+}
+
+// Matrix-pool entries an op needs under the opcode it will get.
+static int pool_entries(const FusedOp& o) {
+  const bool sp = tuning().tile_special;
+  auto is = [&](int e, double re, double im) { return o.m[e].x == re && o.m[e].y == im; };
+  switch (o.kind) {
+    case TG_SWAP1: return 0;
+    case TG_PHASE: return (sp && (is(0, -1, 0) || is(0, 0, 1) || is(0, 0, -1))) ? 0 : 1;
+    case TG_ANTI1: return (sp && is(1, 0, -1) && is(2, 0, 1)) ? 0 : 4;
+    case TG_DENSE2: return 16;
+    default: return 4;
+  }
+}
+
+// Split one pass's ops (list order) into register groups of <= kGroupBits target tile bits and
+// write the gate stream.  Ops that do not fit the argument budget stay un-emitted (they and
+// everything that depends on them wait for the next launch).
+static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_t>& members,
+                        const std::vector<int>& high, int T, TileArgs* a, std::vector<char>* emitted) {
+  const int low = kTileLow;
+  auto tile_pos = [&](int b) -> int {
+    if (b < low) return b;
+    for (size_t j = 0; j < high.size(); ++j) if (high[j] == b) return low + (int)j;
+    return -1;
+  };
+  std::vector<char> done(members.size(), 0);
+  size_t left = members.size();
+  a->ngates = 0;
+  int pool = 0;                       // next free matrix entry; 3 spare entries stay at the end
+  while (left) {
+    std::vector<int> S;               // tile bits of this group
+    std::vector<size_t> grp;          // indices into members
+    u64 blocked = 0;
+    // Budget estimate in half units: a phase gate that may be merged with others (OPC_DIAGR) is
+    // counted as half a descriptor and half a pool entry; the exact budget is enforced when the
+    // group is written out (a group that overflows is cut there, the rest waits for the next pass).
+    int slots2 = 0, pool2 = 0;
+    const bool merge_on = tuning().tile_merge_diag != 0;
+    for (size_t mi = 0; mi < members.size(); ++mi) {
+      if (done[mi]) continue;
+      const FusedOp& o = ops[members[mi]];
+      const u64 qm = op_qmask(o);
+      bool ok = !(blocked & qm);
+      int need[2], nneed = 0;
+      const bool mergeable = merge_on && o.kind == TG_PHASE && pool_entries(o) == 1;
+      if (ok) {
+        for (int t = 0; t < o.ntargets; ++t) {
+          const int p = tile_pos(o.target[t]);
+          if (std::find(S.begin(), S.end(), p) == S.end()) need[nneed++] = p;
+        }
+        if ((int)S.size() + nneed > kGroupBits) ok = false;
+        if (2 * (a->ngates + 1) + slots2 + (mergeable ? 1 : 2) > 2 * kTileMaxGates || (int)grp.size() + 1 > 255) ok = false;
+        if (2 * pool + pool2 + (mergeable ? 1 : 2 * pool_entries(o)) > 2 * (kTileMaxMat - 3)) ok = false;
+      }
+      if (!ok) { blocked |= qm; continue; }
+      for (int t = 0; t < nneed; ++t) S.push_back(need[t]);
+      grp.push_back(mi);
+      slots2 += mergeable ? 1 : 2;
+      pool2 += mergeable ? 1 : 2 * pool_entries(o);
+    }
+    if (grp.empty()) break;           // argument budget exhausted: the rest waits for the next launch
+    // pad the group with the highest unused tile bits (high bits keep LDS accesses contiguous)
+    for (int b = T - 1; (int)S.size() < kGroupBits && b >= 0; --b)
+      if (std::find(S.begin(), S.end(), b) == S.end()) S.push_back(b);
+    std::sort(S.begin(), S.end());
+    auto reg_pos = [&](int tile_bit) -> int {
+      for (int j = 0; j < kGroupBits; ++j) if (S[j] == tile_bit) return j;
+      return -1;
+    };
+    TileGate hd;
+    std::memset(&hd, 0, sizeof hd);
+    hd.opcode = OPC_GROUP;
+    hd.blk_mask = (uint16_t)(S[0] | (S[1] << 4) | (S[2] << 8));
+    const int hd_at = a->ngates++;
+    int n_emitted = 0;
+    auto emit = [&](TileGate g, const double2* m, int nm) {
+      if (nm) {
+        g.mat = (uint16_t)pool;
+        for (int e = 0; e < nm; ++e) a->mat[pool + e] = m[e];
+        pool += nm;
+      }
+      put_gate(a, a->ngates++, g);
+      ++n_emitted;
+    };
+    // Phase gates with ONE register bit and the same predicate (lane bits + outer bits) are merged
+    // (the QFT's CR(k, a), CR(k, b), CR(k, c) for the group's register bits a, b, c): diagonal
+    // gates commute with everything except a non-diagonal gate on one of their bits, so an open
+    // accumulator is written out before such a gate on a register bit it has touched, or at the
+    // end of the group.  One descriptor instead of up to three: the gate loop is scalar-issue bound.
+    struct Acc { uint16_t blk; u64 outer; double2 phi[3]; unsigned touched; int count; TileGate single; };
+    std::vector<Acc> open;
+    bool cut = false;
+    auto flush = [&](size_t i) {
+      const Acc acc = open[i];
+      open.erase(open.begin() + (long)i);
+      if (acc.count == 1) { emit(acc.single, &acc.phi[__builtin_ctz(acc.touched)], 1); return; }
+      TileGate g;
+      std::memset(&g, 0, sizeof g);
+      g.blk_mask = acc.blk;
+      g.outer_mask = acc.outer;
+      double2 m[3];
+      int nm = 0;
+      for (int r = 0; r < 3; ++r) if (acc.touched & (1u << r)) m[nm++] = acc.phi[r];
+      if (nm == 1) g.opcode = (uint8_t)(OPC_PHASE + acc.touched);
+      else g.opcode = (uint8_t)(OPC_DIAGR + (acc.touched == 3 ? 0 : acc.touched == 5 ? 1 : acc.touched == 6 ? 2 : 3));
+      emit(g, m, nm);
+    };
+    for (size_t mi : grp) {
+      const FusedOp& o = ops[members[mi]];
+      TileGate g;
+      std::memset(&g, 0, sizeof g);
+      unsigned reg_mask = 0;
+      int ctrl_reg = -1;
+      auto require_one = [&](int qubit) {      // a control / phase bit
+        const int p = tile_pos(qubit);
+        if (p < 0) { g.outer_mask |= 1ull << qubit; return; }
+        const int r = reg_pos(p);
+        if (r >= 0) { reg_mask |= 1u << r; ctrl_reg = r; }
+        else g.blk_mask |= (uint16_t)(1u << p);
+      };
+      auto is = [&](int e, double re, double im) { return o.m[e].x == re && o.m[e].y == im; };
+      const bool sp = tuning().tile_special;
+      {   // exact budget: descriptors and pool entries written so far + what the open runs will need
+        int reserve_pool = 0;
+        for (const Acc& acc : open) reserve_pool += __builtin_popcount(acc.touched);
+        if (a->ngates + (int)open.size() + 1 > kTileMaxGates ||
+            pool + reserve_pool + std::max(1, pool_entries(o)) > kTileMaxMat - 3) { cut = true; break; }
+      }
+      done[mi] = 1;
+      (*emitted)[mi] = 1;
+      --left;
+      if (o.kind == TG_PHASE) {
+        for (int t = 0; t < o.nbits; ++t) require_one(o.bits[t]);
+        const int fam = !sp ? OPC_PHASE : (is(0, -1, 0) ? OPC_PHASE_NEG : (is(0, 0, 1) ? OPC_PHASE_I : (is(0, 0, -1) ? OPC_PHASE_NI : OPC_PHASE)));
+        g.opcode = (uint8_t)(fam + reg_mask);
+        if (tuning().tile_merge_diag && fam == OPC_PHASE && __builtin_popcount(reg_mask) == 1) {
+          const int r = __builtin_ctz(reg_mask);
+          size_t i = 0;
+          while (i < open.size() && !(open[i].blk == g.blk_mask && open[i].outer == g.outer_mask)) ++i;
+          if (i == open.size()) {
+            Acc acc;
+            acc.blk = g.blk_mask; acc.outer = g.outer_mask; acc.touched = 0; acc.count = 0; acc.single = g;
+            for (int e = 0; e < 3; ++e) acc.phi[e] = make_double2(1.0, 0.0);
+            open.push_back(acc);
+          }
+          Acc& acc = open[i];
+          const double2 f = acc.phi[r], m = o.m[0];
+          acc.phi[r] = make_double2(f.x * m.x - f.y * m.y, f.x * m.y + f.y * m.x);
+          acc.touched |= 1u << r;
+          ++acc.count;
+          continue;
+        }
+      } else if (o.kind == TG_DENSE2) {
+        g.opcode = (uint8_t)(OPC_DENSE2 + 3 * reg_pos(tile_pos(o.target[0])) + reg_pos(tile_pos(o.target[1])));
+      } else {
+        const int J = reg_pos(tile_pos(o.target[0]));
+        if (o.control >= 0) require_one(o.control);
+        int fam = o.kind == TG_DENSE1 ? OPC_DENSE1 : (o.kind == TG_SWAP1 ? OPC_SWAP1 : OPC_ANTI1);
+        if (sp && o.kind == TG_DENSE1 && o.m[0].y == 0 && o.m[1].y == 0 && o.m[2].y == 0 && o.m[3].y == 0) fam = OPC_REAL1;
+        if (sp && o.kind == TG_ANTI1 && is(1, 0, -1) && is(2, 0, 1)) fam = OPC_YLIKE1;
+        g.opcode = (uint8_t)(fam + opc_1q_variant(J, ctrl_reg));
+      }
+      if (o.kind != TG_PHASE) {               // a non-diagonal gate: its targets end the open phase runs on them
+        unsigned tmask = 0;
+        for (int t = 0; t < o.ntargets; ++t) tmask |= 1u << reg_pos(tile_pos(o.target[t]));
+        for (size_t i = open.size(); i-- > 0;) if (open[i].touched & tmask) flush(i);
+      }
+      emit(g, o.m, std::min(pool_entries(o), o.nm));
+    }
+    while (!open.empty()) flush(0);
+    hd.count = (uint8_t)n_emitted;
+    put_gate(a, hd_at, hd);
+    if (cut) break;                   // argument budget exhausted inside the group
+  }
+}
+
+// Greedy pass builder.  Ops are taken in list order; an op that does not fit the current tile
+// blocks its qubits, and later ops on blocked qubits wait for the next pass, so any two ops
+// sharing a qubit keep their order (ops on disjoint qubits commute).
+static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_passes) {
+  const int k = c->k;
+  const Tuning& tune = tuning();
+  const int T = k < kTileBitsMax ? k : kTileBitsMax;
+  const int low = kTileLow;
+  const int cap = T - low;                      // tile high-bit capacity
+  std::vector<char> done(ops.size(), 0);
+  size_t remaining = ops.size();
+  size_t first = 0;
+  *n_passes = 0;
+  while (remaining) {
+    std::vector<int> high;                      // chosen high bits
+    std::vector<size_t> members;
+    u64 blocked = 0;
+    while (first < ops.size() && done[first]) ++first;
+    for (size_t i = first; i < ops.size() && (int)members.size() < tune.max_gates_per_pass; ++i) {
+      if (done[i]) continue;
+      const FusedOp& o = ops[i];
+      const u64 qmask = op_qmask(o);
+      bool ok = !(blocked & qmask);
+      int need[2], nneed = 0;
+      if (ok) {
+        for (int t = 0; t < o.ntargets; ++t) {
+          const int b = o.target[t];
+          if (b >= low && std::find(high.begin(), high.end(), b) == high.end()) need[nneed++] = b;
+        }
+        if ((int)high.size() + nneed > cap) ok = false;
+      }
+      if (!ok) { blocked |= qmask; continue; }
+      for (int t = 0; t < nneed; ++t) high.push_back(need[t]);
+      members.push_back(i);
+    }
+    if (members.empty()) return fail(QSIM_ERR_INVALID, "internal: fused planner made no progress");
+    // fill the tile with the lowest unused bits so it always has T bits
+    for (int b = low; (int)high.size() < cap && b < k; ++b)
+      if (std::find(high.begin(), high.end(), b) == high.end()) high.push_back(b);
+    std::sort(high.begin(), high.end());
+    if (tune.debug_skip_gates == 2) for (int j = 0; j < cap; ++j) high[j] = low + j;   // contiguous tiles (floor probe)
+    if (tune.debug_skip_gates == 3) for (int j = 0; j < cap; ++j) high[j] = k - cap + j; // far-strided tiles
+    TileArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.amp = c->amp;
+    for (size_t j = 0; j < high.size(); ++j) a.h[j] = (uint8_t)high[j];
+    std::vector<char> emitted(members.size(), 0);
+    emit_groups(ops, members, high, T, &a, &emitted);
+    size_t n_emitted = 0;
+    double alg_bytes = 0;   // dense 32N, diagonal / controlled / SWAP 16N, CZ/CR 8N
+    for (size_t mi = 0; mi < members.size(); ++mi)
+      if (emitted[mi]) {
+        const FusedOp& o = ops[members[mi]];
+        const int halvings = o.kind == TG_PHASE ? o.nbits : (o.control >= 0 ? 1 : o.halvings);
+        alg_bytes += 32.0 * (double)(amps(c) >> halvings);
+        done[members[mi]] = 1; --remaining; ++n_emitted;
+      }
+    if (!n_emitted) return fail(QSIM_ERR_INVALID, "internal: fused planner emitted nothing");
+    if (tune.debug_stats) {
+      int groups = 0;
+      for (int i = 0; i < a.ngates; ++i) groups += get_gate(&a, i).opcode == OPC_GROUP;
+      std::fprintf(stderr, "[qsim] pass %d: %zu gates, %d groups, %d entries\n", *n_passes, n_emitted, groups, a.ngates);
+    }
+    if (tune.debug_skip_gates) a.ngates = 0;       // profiling aid: load -> LDS -> store only
+    int rc = launch_tile_any(a, T, c, c->stream, alg_bytes);
+    if (rc) return rc;
+    ++*n_passes;
+  }
+  return QSIM_OK;
+}
