@@ -255,6 +255,36 @@ def test_full_size_28q_unitarity_roundtrip(hip):
     dev.close()
 
 
+def test_config2_full_circuit_every_amplitude_vs_c_oracle_28q(hip):
+    """BASELINE config 2 at its full size: the complete 28-qubit depth-40 random 1q+CX circuit
+    (840 gates, the bench workload) through the fused path, every one of the 2^28 amplitudes
+    against the C oracle run on the host cores (about half a minute of CPU work)."""
+    import os
+    from oracle import c_oracle
+    from quantum_simulations_amd.circuit.io import validate_circuit_dict
+    from quantum_simulations_amd.circuits import random_1q_cx_circuit
+    from quantum_simulations_amd.runner.engine import SingleGpuEngine
+    n = 28
+    cd = validate_circuit_dict(random_1q_cx_circuit(n, depth=40))
+    eng = SingleGpuEngine(n)
+    eng.init_zero_state()
+    eng.execute(eng.plan(cd))
+    assert abs(eng.norm2() - 1.0) < 1e-10
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    c_oracle.set_threads(max(1, min(16, cores)))
+    want = c_oracle.simulate(cd)
+    worst = 0.0
+    step = 1 << 24
+    for off in range(0, 1 << n, step):
+        got = eng.state.download(off, step)
+        worst = max(worst, float(np.max(np.abs(got - want[off:off + step]))))
+    eng.close()
+    assert worst < ATOL_CIRCUIT, worst
+
+
 # ---------------------------------------------------------------- fused LDS-tile passes
 def _random_ops(n, n_ops, seed):
     rng = np.random.default_rng(seed)
