@@ -98,6 +98,32 @@ __global__ void k_unpack_bits(double2* __restrict__ dst, const double2* __restri
     dst[expand_index(j, npos, p0, p1, p2) | value_off] = ld_amp<true>(src + j);
 }
 
+// All slabs in one pass: amplitude i goes to slab pattern(i) at its compressed index (and back).
+// Consecutive lanes read consecutive amplitudes, and the <= 8 slabs a wave feeds each receive a
+// contiguous run, so reads and writes are whole 128-B lines for ANY choice of bits -- the
+// per-pattern kernels above touch 16 B of every line when a selected bit is below 3
+// (tools/relayout_probe.py: 0.7-1.0 TB/s instead of 4.5-5; the gather side of unpack with lanes of
+// one line 8 apart still runs at 2.6-3.5 TB/s).  `skip` = the pattern that stays.
+__device__ __forceinline__ u64 drop_bit(u64 x, int p) { return ((x >> (p + 1)) << p) | (x & ((1ull << p) - 1)); }
+template <bool PACK>
+__global__ void k_slabs_all(double2* __restrict__ state, double2* __restrict__ buf, u64 n, int m,
+                            int b0, int b1, int b2, int s_hi, int s_mid, int s_lo, int slab_bits, int skip) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int p = (int)((i >> b0) & 1);
+    if (m > 1) p |= (int)((i >> b1) & 1) << 1;
+    if (m > 2) p |= (int)((i >> b2) & 1) << 2;
+    if (p == skip) continue;
+    u64 j = i;
+    if (m > 2) j = drop_bit(j, s_hi);
+    if (m > 1) j = drop_bit(j, s_mid);
+    j = drop_bit(j, s_lo);
+    double2* const slot = buf + (((u64)p << slab_bits) | j);
+    if (PACK) st_amp<true>(slot, ld_amp<true>(state + i));
+    else st_amp<true>(state + i, ld_amp<true>(slot));
+  }
+}
+
 // exchange slab (bits pos == a_off pattern) of chunk A with slab (bits pos == b_off pattern) of chunk B
 __global__ void k_swap_slabs(double2* __restrict__ a, double2* __restrict__ b, u64 n_slab,
                              int npos, int p0, int p1, int p2, u64 a_off, u64 b_off) {

@@ -396,6 +396,37 @@ int qsim_unpack_bits(qsim_chunk* dst, int m, const int32_t* bits, int pattern, c
   return QSIM_OK;
 }
 
+static int slabs_all(qsim_chunk* state, int m, const int32_t* bits, qsim_chunk* buf, int skip_pattern, bool pack,
+                     const char* what) {
+  int rc = check_chunk(state, what);
+  if (rc || (rc = check_chunk(buf, what))) return rc;
+  int pos[3];
+  u64 voff, n_slab;
+  if ((rc = slab_args(state, m, bits, 0, buf, 0, pos, &voff, &n_slab))) return rc;
+  if (amps(buf) < amps(state)) return fail(QSIM_ERR_INVALID, "%s: the buffer must hold all 2^%d slabs", what, m);
+  if (skip_pattern < -1 || skip_pattern >= (1 << m)) return fail(QSIM_ERR_INVALID, "%s: skip pattern out of range", what);
+  HIP_TRY(hipSetDevice(state->device));
+  const int b0 = bits[0], b1 = m > 1 ? bits[1] : 0, b2 = m > 2 ? bits[2] : 0;
+  const int s_lo = pos[0], s_mid = m > 1 ? pos[1] : 0, s_hi = m > 2 ? pos[2] : 0;   // pos is sorted ascending
+  const u64 n = amps(state);
+  if (pack)
+    hipLaunchKernelGGL((k_slabs_all<true>), dim3(stream_grid(n)), dim3(kBlock), 0, state->stream, state->amp, buf->amp,
+                       n, m, b0, b1, b2, s_hi, s_mid, s_lo, state->k - m, skip_pattern);
+  else
+    hipLaunchKernelGGL((k_slabs_all<false>), dim3(stream_grid(n)), dim3(kBlock), 0, state->stream, state->amp, buf->amp,
+                       n, m, b0, b1, b2, s_hi, s_mid, s_lo, state->k - m, skip_pattern);
+  HIP_TRY(hipGetLastError());
+  return QSIM_OK;
+}
+
+int qsim_pack_all(const qsim_chunk* src, int m, const int32_t* bits, qsim_chunk* buf, int skip_pattern) {
+  return slabs_all(const_cast<qsim_chunk*>(src), m, bits, buf, skip_pattern, true, "qsim_pack_all");
+}
+
+int qsim_unpack_all(qsim_chunk* dst, int m, const int32_t* bits, const qsim_chunk* buf, int skip_pattern) {
+  return slabs_all(dst, m, bits, const_cast<qsim_chunk*>(buf), skip_pattern, false, "qsim_unpack_all");
+}
+
 int qsim_swap_global_local(qsim_chunk* const* chunks, int n_chunks, const int32_t* global_bits,
                            const int32_t* local_bits, int m) {
   if (!chunks || !global_bits || !local_bits) return fail(QSIM_ERR_INVALID, "qsim_swap_global_local: null argument");

@@ -119,6 +119,12 @@ class HipShardBackend:
     def unpack_bits(self, bits, pattern: int, src: str, src_offset: int) -> None:
         self.chunk("state").unpack_bits(bits, pattern, self.chunk(src), src_offset)
 
+    def pack_all(self, bits, dst: str, skip_pattern: int) -> None:
+        self.chunk("state").pack_all(bits, self.chunk(dst), skip_pattern)
+
+    def unpack_all(self, bits, src: str, skip_pattern: int) -> None:
+        self.chunk("state").unpack_all(bits, self.chunk(src), skip_pattern)
+
     def closed_form_error(self, kind: str, n_total: int, base_index: int, log_to_phys) -> float:
         return self.chunk("state").max_abs_err_closed_form(kind, n_total, base_index, log_to_phys)
 
@@ -308,18 +314,16 @@ class DistributedEngine:
         mine = sum(((self.rank >> (g - self.k)) & 1) << i for i, g in enumerate(glo))
         send, recv = self.backend.tensor("buf0"), self.backend.tensor("buf1")
         transfers = []
+        self.backend.pack_all(loc, "buf0", mine)       # slab d at offset d * 2^(k-m); one HBM pass
         for d in range(1 << m):
             if d == mine:
                 continue
             peer = self.rank
             for i, g in enumerate(glo):
                 peer = (peer & ~(1 << (g - self.k))) | (((d >> i) & 1) << (g - self.k))
-            self.backend.pack_bits(loc, d, "buf0", d << (self.k - m))
             transfers.append((peer, send[d * slab:(d + 1) * slab], recv[d * slab:(d + 1) * slab]))
         self._exchange(transfers)
-        for d in range(1 << m):
-            if d != mine:
-                self.backend.unpack_bits(loc, d, "buf1", d << (self.k - m))
+        self.backend.unpack_all(loc, "buf1", mine)
 
     # -- one gate with at least one global qubit ---------------------------------------------------
     def apply_nonlocal(self, qs, U) -> None:

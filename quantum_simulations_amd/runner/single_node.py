@@ -130,13 +130,19 @@ def _apply_step(state: DeviceChunk, chunks: list[DeviceChunk], local_ops, nonloc
         state.apply_ops(local_ops)
     if nonlocal_ops:
         pairs = _relayout_pairs(nonlocal_ops, k)
-        if pairs is not None and len(pairs) <= 3:   # a staging SWAP list: ONE all-to-all re-layout
+        if pairs is not None and len(pairs) <= 3 and min(lo for lo, _ in pairs) < _SUBLINE_BITS:
+            # a local bit inside a 128-B line: the slab exchange would touch 16 B of every line
+            # (tools/relayout_probe.py: 0.65 TB/s); on ONE allocation the same permutation is a
+            # set of SWAP gates between index bits of the whole state = one fused tile pass
+            state.apply_ops(nonlocal_ops)
+        elif pairs is not None and len(pairs) <= 3:   # a staging SWAP list: ONE all-to-all re-layout
             gpu_nonlocal.swap_global_local(chunks, [hi - k for _, hi in pairs], [lo for lo, _ in pairs])
         else:
             _process_nonlocal_groups(chunks, nonlocal_ops, k)
 
 
 _SWAP_U = None
+_SUBLINE_BITS = 3      # index bits 0-2: 8 amplitudes = one 128-B line
 
 
 def _relayout_pairs(nonlocal_ops, k: int):

@@ -68,6 +68,18 @@ class CpuShardBackend:
         sel = self._slab_index(bits, pattern)
         self._c("state")[sel] = self._c(src)[src_offset:src_offset + sel.size]
 
+    def pack_all(self, bits, dst: str, skip_pattern: int) -> None:
+        slab = 1 << (self.k - len(bits))
+        for d in range(1 << len(bits)):
+            if d != skip_pattern:
+                self.pack_bits(bits, d, dst, d * slab)
+
+    def unpack_all(self, bits, src: str, skip_pattern: int) -> None:
+        slab = 1 << (self.k - len(bits))
+        for d in range(1 << len(bits)):
+            if d != skip_pattern:
+                self.unpack_bits(bits, d, src, d * slab)
+
     def closed_form_error(self, kind, n_total, base_index, log_to_phys) -> float:
         x = base_index + np.arange(1 << self.k, dtype=np.int64)
         y = np.zeros_like(x)

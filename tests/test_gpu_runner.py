@@ -146,6 +146,68 @@ def test_swap_global_local_relayout():
         gpu_nonlocal.swap_global_local(chunks, [0, 0], [0, 1])
 
 
+def test_pack_all_matches_per_pattern_slabs():
+    """qsim_pack_all / qsim_unpack_all (one pass, every slab) against the per-pattern forms, for
+    bit choices inside and outside a 128-B line, with and without a slab that stays."""
+    from quantum_simulations_amd.kernel.device import DeviceChunk
+    n = 13
+    rng = np.random.default_rng(21)
+    psi = (rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)).astype(np.complex128)
+    state = DeviceChunk.from_numpy(psi)
+    one, all_ = DeviceChunk.empty(n), DeviceChunk.empty(n)
+    for bits in ([12], [0], [2, 1], [0, 7], [11, 3, 9], [0, 1, 2], [2, 12, 0], [5, 6, 7]):
+        m = len(bits)
+        slab = 1 << (n - m)
+        for skip in (-1, 0, (1 << m) - 1):
+            one.upload(np.zeros(1 << n, dtype=np.complex128))
+            all_.upload(np.zeros(1 << n, dtype=np.complex128))
+            for d in range(1 << m):
+                if d != skip:
+                    state.pack_bits(bits, d, one, d * slab)
+            state.pack_all(bits, all_, skip)
+            np.testing.assert_array_equal(all_.download(), one.download(), err_msg=f"{bits} skip={skip}")
+            back = DeviceChunk.from_numpy(np.full(1 << n, 7.0 + 0j))
+            back.unpack_all(bits, all_, skip)
+            got = back.download()
+            stay = np.ones(1 << n, dtype=bool)
+            if skip >= 0:
+                idx = np.arange(1 << n)
+                for i, b in enumerate(bits):
+                    stay &= ((idx >> b) & 1) == ((skip >> i) & 1)
+            else:
+                stay[:] = False
+            np.testing.assert_array_equal(got[~stay], psi[~stay], err_msg=f"{bits} skip={skip}")
+            assert np.all(got[stay] == 7.0)
+            back.close()
+    with pytest.raises(ValueError):
+        state.pack_all([0, 0], all_)
+    with pytest.raises(ValueError):
+        state.pack_all([1], DeviceChunk.empty(n - 1))
+    for c in (state, one, all_):
+        c.close()
+
+
+def test_runner_relayout_on_subline_bits(runner):
+    """A staging SWAP list whose local qubit lies inside a 128-B line takes the fused-pass route
+    (SWAP gates on the whole allocation); result equals the pairwise butterflies."""
+    from quantum_simulations_amd.kernel.device import DeviceChunk
+    n, k = 10, 6
+    rng = np.random.default_rng(12)
+    psi = (rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)).astype(np.complex128)
+    SW = orc.gate_matrix("SWAP")
+    for pairs in ([(0, 7)], [(2, 6), (5, 9)], [(1, 8), (0, 6), (2, 7)]):
+        want = psi.copy()
+        for lo, hi in pairs:
+            orc.apply_2q(want, lo, hi, SW)
+        state = DeviceChunk.from_numpy(psi)
+        chunks = [state.view(c << k, k) for c in range(1 << (n - k))]
+        runner._apply_step(state, chunks, [], [([lo, hi], SW) for lo, hi in pairs], k)
+        np.testing.assert_allclose(state.download(), want, rtol=0, atol=1e-15)
+        for c in chunks:
+            c.close()
+        state.close()
+
+
 # ---- step-level checkpoint / resume (SURVEY 8f rank 3) ------------------------------------------
 def test_checkpoint_resume_after_injected_stop(tmp_path):
     """test_recovery_crash.py tests 2-3 on the GPU runner: stop after a step, run again on the same
