@@ -9,23 +9,25 @@ basis raises ValueError naming the gate.
 """
 from __future__ import annotations
 
-SUPPORTED_BASIS = ["h", "x", "y", "z", "s", "t", "ry", "cx", "cz", "swap", "cy"]
-
-_GATE_OF = {"h": "H", "x": "X", "y": "Y", "z": "Z", "s": "S", "t": "T", "ry": "RY",
-            "cx": "CNOT", "cnot": "CNOT", "swap": "SWAP", "cz": "CZ", "cy": "CY"}
-_IGNORED = ("barrier", "measure", "reset", "delay", "id")
+# (qiskit instruction name, gate of the circuit contract, name of its angle parameter)
+_TABLE = (("h", "H", None), ("x", "X", None), ("y", "Y", None), ("z", "Z", None), ("s", "S", None),
+          ("t", "T", None), ("ry", "RY", "theta"), ("cx", "CNOT", None), ("cz", "CZ", None),
+          ("swap", "SWAP", None), ("cy", "CY", None))
+SUPPORTED_BASIS = [name for name, _, _ in _TABLE]
+_GATE_OF = {name: (gate, angle) for name, gate, angle in _TABLE}
+_GATE_OF["cnot"] = _GATE_OF["cx"]
+_NOT_GATES = ("barrier", "measure", "reset", "delay", "id")
 
 
 def qiskit_to_dict(qc) -> dict:
     gates = []
     for item in qc.data:
-        op = item.operation
-        name = op.name.lower()
-        if name in _IGNORED:
+        name = item.operation.name.lower()
+        if name in _NOT_GATES:
             continue
         if name not in _GATE_OF:
             raise ValueError(f"Unsupported gate '{name}'. Transpile to basis {SUPPORTED_BASIS} first.")
-        params = {"theta": float(op.params[0])} if name == "ry" else {}
-        gates.append({"qubits": [qc.find_bit(q).index for q in item.qubits],
-                      "gate": _GATE_OF[name], "params": params})
+        gate, angle = _GATE_OF[name]
+        gates.append({"qubits": [qc.find_bit(q).index for q in item.qubits], "gate": gate,
+                      "params": {angle: float(item.operation.params[0])} if angle else {}})
     return {"number_of_qubits": qc.num_qubits, "gates": gates}

@@ -1,19 +1,23 @@
-"""Step log of a checkpointed run: the reference's `wal.json` document.
+"""Step log of a checkpointed run, stored as the reference's `wal.json` document.
 
-Same file and field layout as wenbo_engine/wal/wal.py:25-93 -- {"circuit_hash", "committed_buf",
-"done_steps"} rewritten atomically (tmp + fsync + rename) -- and the same circuit identity
-(wal.py:17-22: sha256 of the validated circuit dict, first 16 hex digits), so either side can
-resume a run the other one checkpointed.  The GPU runner commits every `checkpoint_every` steps
-instead of every step (the state lives in HBM; a checkpoint is a full download).
+Interoperates with wenbo_engine/wal/wal.py:25-93: the file holds exactly the three fields
+"circuit_hash", "committed_buf" ("a" | "b") and "done_steps", is replaced atomically, and the
+circuit identity is that module's (wal.py:17-22: sha256 over the validated circuit dict, first 16
+hex digits) -- so either side can resume a run the other one checkpointed.  The GPU runner
+commits every `checkpoint_every` steps instead of every step: the state lives in HBM and a
+checkpoint is a full download (runner/single_node.py).
 """
 from __future__ import annotations
 
 import hashlib
 import json
 import os
+import tempfile
 from pathlib import Path
 
 from quantum_simulations_amd.circuit.io import validate_circuit_dict
+
+_FIELDS = {"circuit_hash": "", "committed_buf": "a", "done_steps": 0}
 
 
 def circuit_hash(circuit_dict: dict) -> str:
@@ -21,41 +25,39 @@ def circuit_hash(circuit_dict: dict) -> str:
     return hashlib.sha256(canonical.encode()).hexdigest()[:16]
 
 
+def _replace_json(path: Path, doc: dict) -> None:
+    """Write-to-temp, fsync, rename: readers see the old or the new document, never a torn one."""
+    fd, tmp = tempfile.mkstemp(dir=path.parent, prefix=path.name + ".", suffix=".tmp")
+    with os.fdopen(fd, "w") as f:
+        json.dump(doc, f, indent=2)
+        f.flush()
+        os.fsync(f.fileno())
+    os.replace(tmp, path)
+
+
 class WAL:
+    """`WAL(path, circuit_dict)` opens or creates the log; `done_steps` / `committed_buf` say where
+    to resume; `commit_step(i, buf)` records that steps 0..i are in buffer `buf`."""
+
     def __init__(self, path: str | Path, circuit_dict: dict | None = None):
         self.path = Path(path)
         self.path.parent.mkdir(parents=True, exist_ok=True)
-        mine = circuit_hash(circuit_dict) if circuit_dict else None
-        if self.path.exists():
-            with open(self.path) as f:
-                self._doc = json.load(f)
-            theirs = self._doc.get("circuit_hash")
-            if mine and theirs and mine != theirs:
-                raise ValueError(f"WAL circuit hash mismatch — different circuit? WAL={theirs} vs new={mine}")
-        else:
-            self._doc = {"circuit_hash": mine or "", "committed_buf": "a", "done_steps": 0}
-            self._store()
+        identity = circuit_hash(circuit_dict) if circuit_dict else None
+        if not self.path.exists():
+            self._doc = dict(_FIELDS, circuit_hash=identity or "")
+            _replace_json(self.path, self._doc)
+            return
+        self._doc = json.loads(self.path.read_text())
+        logged = self._doc.get("circuit_hash")
+        if identity and logged and identity != logged:
+            raise ValueError(f"WAL circuit hash mismatch — different circuit? WAL={logged} vs new={identity}")
 
-    def _store(self) -> None:
-        tmp = self.path.with_suffix(".tmp")
-        with open(tmp, "w") as f:
-            f.write(json.dumps(self._doc, indent=2))
-            f.flush()
-            os.fsync(f.fileno())
-        os.replace(tmp, self.path)
-
-    @property
-    def committed_buf(self) -> str:
-        return self._doc.get("committed_buf", "a")
-
-    @property
-    def done_steps(self) -> int:
-        return self._doc.get("done_steps", 0)
+    committed_buf = property(lambda self: self._doc.get("committed_buf", _FIELDS["committed_buf"]))
+    done_steps = property(lambda self: self._doc.get("done_steps", _FIELDS["done_steps"]))
 
     def commit_step(self, step_idx: int, new_buf: str) -> None:
-        self._doc["committed_buf"] = new_buf
-        self._doc["done_steps"] = step_idx + 1
-        self._store()
+        self._doc.update(committed_buf=new_buf, done_steps=step_idx + 1)
+        _replace_json(self.path, self._doc)
 
-    def close(self) -> None:
-        pass
+    def close(self) -> None:       # nothing is held open; kept because callers of the reference call it
+        return None
