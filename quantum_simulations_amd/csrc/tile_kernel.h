@@ -286,7 +286,8 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
     const int ge = gi + ((hd.x >> 8) & 0xFF);
     const unsigned tb = insert_zero(insert_zero(insert_zero((unsigned)tid, s0), s1), s2);
     const unsigned b0 = 1u << s0, b1 = 1u << s1, b2 = 1u << s2;
-    double2 x0, x1, x2, x3, x4, x5, x6, x7;
+    // (zero for the surplus threads of tiny tiles: they run the gate cases too, but never write back)
+    double2 x0 = make_double2(0.0, 0.0), x1 = x0, x2 = x0, x3 = x0, x4 = x0, x5 = x0, x6 = x0, x7 = x0;
     if (live) {
       x0 = lds[lds_slot(tb)];            x1 = lds[lds_slot(tb | b0)];
       x2 = lds[lds_slot(tb | b1)];       x3 = lds[lds_slot(tb | b1 | b0)];
