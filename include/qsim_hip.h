@@ -106,9 +106,13 @@ int qsim_unpack_bits(qsim_chunk* dst, int m, const int32_t* bits, int pattern,
 /* All 2^m slabs in one pass over the shard: slab p lands at buf[p * 2^(k-m) ...) (`buf` holds k
  * qubits); the slab `skip_pattern` (the part that stays on this rank; -1 = none) is left out.
  * Whole 128-B lines are read and written for every choice of bits, unlike the per-pattern form
- * when a bit is below 3.                                                                  */
-int qsim_pack_all(const qsim_chunk* src, int m, const int32_t* bits, qsim_chunk* buf, int skip_pattern);
-int qsim_unpack_all(qsim_chunk* dst, int m, const int32_t* bits, const qsim_chunk* buf, int skip_pattern);
+ * when a bit is below 3.  `piece` of `n_pieces` (1, 2, 4 or 8) restricts the call to the same
+ * contiguous 1/n_pieces sub-range of every slab, so runner/distributed.py can overlap packing,
+ * the RCCL exchange and unpacking piece by piece.                                          */
+int qsim_pack_all(const qsim_chunk* src, int m, const int32_t* bits, qsim_chunk* buf, int skip_pattern,
+                  int piece, int n_pieces);
+int qsim_unpack_all(qsim_chunk* dst, int m, const int32_t* bits, const qsim_chunk* buf, int skip_pattern,
+                    int piece, int n_pieces);
 
 /* All-to-all re-layout among the 2^g chunks of ONE device (chunks[c] = chunk index c): swaps
  * local qubit local_bits[i] with chunk-index bit global_bits[i] for i < m (m <= 3) -- the merged

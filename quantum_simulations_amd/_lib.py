@@ -60,8 +60,8 @@ SIGNATURES = {
     "qsim_unpack_half": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "qsim_pack_bits": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_uint64]),
     "qsim_unpack_bits": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_uint64]),
-    "qsim_pack_all": (C.c_int, [_P, C.c_int, _P, _P, C.c_int]),
-    "qsim_unpack_all": (C.c_int, [_P, C.c_int, _P, _P, C.c_int]),
+    "qsim_pack_all": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int]),
+    "qsim_unpack_all": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int]),
     "qsim_swap_global_local": (C.c_int, [_P, C.c_int, _P, _P, C.c_int]),
     "qsim_sync": (C.c_int, [_P]),
     "qsim_norm2": (C.c_int, [_P, C.POINTER(C.c_double)]),

@@ -107,9 +107,16 @@ __global__ void k_unpack_bits(double2* __restrict__ dst, const double2* __restri
 __device__ __forceinline__ u64 drop_bit(u64 x, int p) { return ((x >> (p + 1)) << p) | (x & ((1ull << p) - 1)); }
 template <bool PACK>
 __global__ void k_slabs_all(double2* __restrict__ state, double2* __restrict__ buf, u64 n, int m,
-                            int b0, int b1, int b2, int s_hi, int s_mid, int s_lo, int slab_bits, int skip) {
+                            int b0, int b1, int b2, int s_hi, int s_mid, int s_lo, int slab_bits, int skip,
+                            int n_piece_bits, int pb0, int pb1, int pb2, int piece) {
+  // A piece = the amplitudes whose top `n_piece_bits` non-selected index bits equal `piece`: the
+  // same contiguous sub-range of every slab, so the exchange can be pipelined piece by piece.
   const u64 stride = (u64)gridDim.x * blockDim.x;
-  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+    u64 i = t;
+    if (n_piece_bits > 0) i = (((i >> pb0) << (pb0 + 1)) | (i & ((1ull << pb0) - 1))) | ((u64)(piece & 1) << pb0);
+    if (n_piece_bits > 1) i = (((i >> pb1) << (pb1 + 1)) | (i & ((1ull << pb1) - 1))) | ((u64)((piece >> 1) & 1) << pb1);
+    if (n_piece_bits > 2) i = (((i >> pb2) << (pb2 + 1)) | (i & ((1ull << pb2) - 1))) | ((u64)((piece >> 2) & 1) << pb2);
     int p = (int)((i >> b0) & 1);
     if (m > 1) p |= (int)((i >> b1) & 1) << 1;
     if (m > 2) p |= (int)((i >> b2) & 1) << 2;

@@ -396,8 +396,8 @@ int qsim_unpack_bits(qsim_chunk* dst, int m, const int32_t* bits, int pattern, c
   return QSIM_OK;
 }
 
-static int slabs_all(qsim_chunk* state, int m, const int32_t* bits, qsim_chunk* buf, int skip_pattern, bool pack,
-                     const char* what) {
+static int slabs_all(qsim_chunk* state, int m, const int32_t* bits, qsim_chunk* buf, int skip_pattern, int piece,
+                     int n_pieces, bool pack, const char* what) {
   int rc = check_chunk(state, what);
   if (rc || (rc = check_chunk(buf, what))) return rc;
   int pos[3];
@@ -405,26 +405,39 @@ static int slabs_all(qsim_chunk* state, int m, const int32_t* bits, qsim_chunk* 
   if ((rc = slab_args(state, m, bits, 0, buf, 0, pos, &voff, &n_slab))) return rc;
   if (amps(buf) < amps(state)) return fail(QSIM_ERR_INVALID, "%s: the buffer must hold all 2^%d slabs", what, m);
   if (skip_pattern < -1 || skip_pattern >= (1 << m)) return fail(QSIM_ERR_INVALID, "%s: skip pattern out of range", what);
+  int piece_bits = 0;
+  while ((1 << piece_bits) < n_pieces) ++piece_bits;
+  if (n_pieces < 1 || (1 << piece_bits) != n_pieces || piece_bits > 3 || piece_bits > state->k - m)
+    return fail(QSIM_ERR_INVALID, "%s: n_pieces must be 1, 2, 4 or 8 and at most the slab length", what);
+  if (piece < 0 || piece >= n_pieces) return fail(QSIM_ERR_INVALID, "%s: piece %d out of range", what, piece);
+  int pb[3] = {0, 0, 0};      // the top piece_bits index bits that are NOT selected, ascending
+  for (int b = state->k - 1, found = 0; b >= 0 && found < piece_bits; --b) {
+    bool selected = false;
+    for (int i = 0; i < m; ++i) selected = selected || bits[i] == b;
+    if (!selected) pb[piece_bits - 1 - found++] = b;
+  }
   HIP_TRY(hipSetDevice(state->device));
   const int b0 = bits[0], b1 = m > 1 ? bits[1] : 0, b2 = m > 2 ? bits[2] : 0;
   const int s_lo = pos[0], s_mid = m > 1 ? pos[1] : 0, s_hi = m > 2 ? pos[2] : 0;   // pos is sorted ascending
-  const u64 n = amps(state);
+  const u64 n = amps(state) >> piece_bits;
   if (pack)
     hipLaunchKernelGGL((k_slabs_all<true>), dim3(stream_grid(n)), dim3(kBlock), 0, state->stream, state->amp, buf->amp,
-                       n, m, b0, b1, b2, s_hi, s_mid, s_lo, state->k - m, skip_pattern);
+                       n, m, b0, b1, b2, s_hi, s_mid, s_lo, state->k - m, skip_pattern, piece_bits, pb[0], pb[1], pb[2], piece);
   else
     hipLaunchKernelGGL((k_slabs_all<false>), dim3(stream_grid(n)), dim3(kBlock), 0, state->stream, state->amp, buf->amp,
-                       n, m, b0, b1, b2, s_hi, s_mid, s_lo, state->k - m, skip_pattern);
+                       n, m, b0, b1, b2, s_hi, s_mid, s_lo, state->k - m, skip_pattern, piece_bits, pb[0], pb[1], pb[2], piece);
   HIP_TRY(hipGetLastError());
   return QSIM_OK;
 }
 
-int qsim_pack_all(const qsim_chunk* src, int m, const int32_t* bits, qsim_chunk* buf, int skip_pattern) {
-  return slabs_all(const_cast<qsim_chunk*>(src), m, bits, buf, skip_pattern, true, "qsim_pack_all");
+int qsim_pack_all(const qsim_chunk* src, int m, const int32_t* bits, qsim_chunk* buf, int skip_pattern, int piece,
+                  int n_pieces) {
+  return slabs_all(const_cast<qsim_chunk*>(src), m, bits, buf, skip_pattern, piece, n_pieces, true, "qsim_pack_all");
 }
 
-int qsim_unpack_all(qsim_chunk* dst, int m, const int32_t* bits, const qsim_chunk* buf, int skip_pattern) {
-  return slabs_all(dst, m, bits, const_cast<qsim_chunk*>(buf), skip_pattern, false, "qsim_unpack_all");
+int qsim_unpack_all(qsim_chunk* dst, int m, const int32_t* bits, const qsim_chunk* buf, int skip_pattern, int piece,
+                    int n_pieces) {
+  return slabs_all(dst, m, bits, const_cast<qsim_chunk*>(buf), skip_pattern, piece, n_pieces, false, "qsim_unpack_all");
 }
 
 int qsim_swap_global_local(qsim_chunk* const* chunks, int n_chunks, const int32_t* global_bits,

@@ -204,14 +204,17 @@ class DeviceChunk:
         b = np.asarray(bits, dtype=np.int32)
         _lib.check(_lib.load().qsim_unpack_bits(self._h, len(b), b.ctypes.data_as(C.c_void_p), int(pattern),
                                                 buf._h, int(buf_offset)))
-    def pack_all(self, bits, buf: "DeviceChunk", skip_pattern: int = -1) -> None:
-        """Every slab of the all-to-all re-layout in one pass (qsim_pack_all)."""
+    def pack_all(self, bits, buf: "DeviceChunk", skip_pattern: int = -1, piece: int = 0, n_pieces: int = 1) -> None:
+        """Every slab of the all-to-all re-layout in one pass (qsim_pack_all); `piece` of `n_pieces`
+        = the same contiguous sub-range of every slab."""
         b = np.asarray(bits, dtype=np.int32)
-        _lib.check(_lib.load().qsim_pack_all(self._h, len(b), b.ctypes.data_as(C.c_void_p), buf._h, int(skip_pattern)))
+        _lib.check(_lib.load().qsim_pack_all(self._h, len(b), b.ctypes.data_as(C.c_void_p), buf._h, int(skip_pattern),
+                                             int(piece), int(n_pieces)))
 
-    def unpack_all(self, bits, buf: "DeviceChunk", skip_pattern: int = -1) -> None:
+    def unpack_all(self, bits, buf: "DeviceChunk", skip_pattern: int = -1, piece: int = 0, n_pieces: int = 1) -> None:
         b = np.asarray(bits, dtype=np.int32)
-        _lib.check(_lib.load().qsim_unpack_all(self._h, len(b), b.ctypes.data_as(C.c_void_p), buf._h, int(skip_pattern)))
+        _lib.check(_lib.load().qsim_unpack_all(self._h, len(b), b.ctypes.data_as(C.c_void_p), buf._h, int(skip_pattern),
+                                               int(piece), int(n_pieces)))
 
 
 def device_count() -> int:

@@ -68,17 +68,23 @@ class CpuShardBackend:
         sel = self._slab_index(bits, pattern)
         self._c("state")[sel] = self._c(src)[src_offset:src_offset + sel.size]
 
-    def pack_all(self, bits, dst: str, skip_pattern: int) -> None:
+    def pack_all(self, bits, dst: str, skip_pattern: int, piece: int = 0, n_pieces: int = 1) -> None:
         slab = 1 << (self.k - len(bits))
+        part = slab // n_pieces
         for d in range(1 << len(bits)):
             if d != skip_pattern:
-                self.pack_bits(bits, d, dst, d * slab)
+                sel = self._slab_index(bits, d)[piece * part:(piece + 1) * part]
+                off = d * slab + piece * part
+                self._c(dst)[off:off + part] = self._c("state")[sel]
 
-    def unpack_all(self, bits, src: str, skip_pattern: int) -> None:
+    def unpack_all(self, bits, src: str, skip_pattern: int, piece: int = 0, n_pieces: int = 1) -> None:
         slab = 1 << (self.k - len(bits))
+        part = slab // n_pieces
         for d in range(1 << len(bits)):
             if d != skip_pattern:
-                self.unpack_bits(bits, d, src, d * slab)
+                sel = self._slab_index(bits, d)[piece * part:(piece + 1) * part]
+                off = d * slab + piece * part
+                self._c("state")[sel] = self._c(src)[off:off + part]
 
     def closed_form_error(self, kind, n_total, base_index, log_to_phys) -> float:
         x = base_index + np.arange(1 << self.k, dtype=np.int64)

@@ -60,9 +60,11 @@ def _worker(rank, world, port, n, staging_modes, errors):
         from tests.cpu_shard_backend import CpuShardBackend
         p = world.bit_length() - 1
         eng = None
-        for staging, method in staging_modes:
+        for mode_no, (staging, method) in enumerate(staging_modes):
+            # re-layouts pipelined in 4 / 2 / 1 pieces (tiny shards: lift the piece-size floor)
             eng = DistributedEngine(n, world, rank, backend=CpuShardBackend(n - p),
-                                    staging=staging, staging_method=method)
+                                    staging=staging, staging_method=method,
+                                    relayout_pieces=(4, 2, 1)[mode_no % 3], min_piece_qubits=1)
             for name, cd in _circuits(n).items():
                 want = orc.simulate(validate_circuit_dict(cd))
                 eng.init_zero_state()

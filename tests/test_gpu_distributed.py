@@ -26,7 +26,8 @@ def _worker(rank, world, port, n, errors):
         from quantum_simulations_amd.runner.distributed import DistributedEngine, HipShardBackend
         p = world.bit_length() - 1
         for staging in (True, False):
-            eng = DistributedEngine(n, world, rank, backend=HipShardBackend(n - p, 0), staging=staging)
+            eng = DistributedEngine(n, world, rank, backend=HipShardBackend(n - p, 0), staging=staging,
+                                    relayout_pieces=4 if world == 2 else 2, min_piece_qubits=1)
             for name, cd in _circuits(n).items():
                 want = orc.simulate(validate_circuit_dict(cd))
                 eng.init_zero_state()

@@ -179,10 +179,29 @@ def test_pack_all_matches_per_pattern_slabs():
             np.testing.assert_array_equal(got[~stay], psi[~stay], err_msg=f"{bits} skip={skip}")
             assert np.all(got[stay] == 7.0)
             back.close()
+            # the same in 2 / 4 / 8 pieces (sub-ranges of every slab, for the pipelined exchange)
+            for n_pieces in (2, 4, 8):
+                all_.upload(np.zeros(1 << n, dtype=np.complex128))
+                for piece in range(n_pieces):
+                    state.pack_all(bits, all_, skip, piece, n_pieces)
+                    part = slab // n_pieces
+                    seen = all_.download()
+                    for d in range(1 << m):       # nothing beyond this piece has been written yet
+                        assert not np.any(seen[d * slab + (piece + 1) * part:(d + 1) * slab]), (bits, n_pieces, piece)
+                np.testing.assert_array_equal(all_.download(), one.download(), err_msg=f"{bits} pieces={n_pieces}")
+                back = DeviceChunk.from_numpy(np.full(1 << n, 7.0 + 0j))
+                for piece in reversed(range(n_pieces)):
+                    back.unpack_all(bits, all_, skip, piece, n_pieces)
+                np.testing.assert_array_equal(back.download(), got, err_msg=f"{bits} pieces={n_pieces}")
+                back.close()
     with pytest.raises(ValueError):
         state.pack_all([0, 0], all_)
     with pytest.raises(ValueError):
         state.pack_all([1], DeviceChunk.empty(n - 1))
+    with pytest.raises(ValueError):
+        state.pack_all([1], all_, -1, 0, 3)          # pieces: 1, 2, 4, 8
+    with pytest.raises(ValueError):
+        state.pack_all([1], all_, -1, 4, 4)
     for c in (state, one, all_):
         c.close()
 
