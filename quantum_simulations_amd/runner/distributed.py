@@ -12,6 +12,7 @@ partitioner and the driver-side sequential partner-group loop (spark_runner.py:1
                                        (the reference runs these as butterflies, staging.py:67-72)
   controlled gate, global control ... ranks whose control bit is 1 apply the 1q gate (locally,
                                        or with one partner when the target is global too)
+  (local ops produced by the two rows above are queued and fused into the next local pass)
   other gates on a global qubit ..... full-shard exchange with the partner rank over one xGMI
                                        link + the partner-chunk kernel (apply_*_pair semantics)
   staging SWAP lists ([p_out<k, p_in>=k], SWAP; staging.py:136-152) of one step are MERGED
@@ -186,6 +187,7 @@ class DistributedEngine:
             raise ValueError("relayout_pieces must be 1, 2, 4 or 8")
         self.relayout_pieces, self.min_piece_qubits = relayout_pieces, min_piece_qubits
         self._passes = self.last_passes = 0
+        self._pending: list = []
 
     # ---- helpers -----------------------------------------------------------------------
     def _rank_bit(self, phys_qubit: int) -> int:
@@ -242,12 +244,28 @@ class DistributedEngine:
         self._finish(self._post(transfers))
         self._comm_done(timer)
 
+    # ---- deferred local work -------------------------------------------------------------------
+    # Global-qubit gates that need no exchange end up as LOCAL ops on this rank (a rank-bit phase,
+    # a diagonal on the local partner qubit, the conditional 1q gate of a global control).  Run one
+    # by one each is a full HBM pass of the shard; queued, they ride in the next fused local pass
+    # (program order is kept: they sit between two local batches), or are flushed before anything
+    # that reads the shard (an exchange, a re-layout, a reduction, a download).
+    def _queue_local(self, op) -> None:
+        self._pending.append(op)
+
+    def _flush_local(self) -> None:
+        if self._pending:
+            ops, self._pending = self._pending, []
+            self._passes += self.backend.apply_ops(ops) or 0
+
     # ---- state ---------------------------------------------------------------------------
     def init_zero_state(self) -> None:
+        self._pending = []
         self.backend.init_zero(self.rank == 0)
         self.l2p = list(range(self.n))
 
     def norm2(self) -> float:
+        self._flush_local()
         t = self.torch.tensor([self.backend.norm2()], dtype=self.torch.float64)
         if self.dist.get_backend() == "nccl":
             t = t.cuda()
@@ -256,6 +274,7 @@ class DistributedEngine:
 
     def state_vector(self) -> np.ndarray:
         """Whole state in LOGICAL qubit order on every rank (small n only: tests, examples)."""
+        self._flush_local()
         local = self.torch.from_numpy(self.backend.download().view(np.float64).copy())
         parts = [self.torch.empty_like(local) for _ in range(self.world)]
         if self.dist.get_backend() == "nccl":
@@ -305,13 +324,15 @@ class DistributedEngine:
         self._passes = 0
         for step in plan.executions[i]:
             self.run_step(step)
+        self._flush_local()
         self.last_passes = self._passes
         self.l2p = list(plan.mappings[i])
         plan.cursor = i + 1
 
     def run_step(self, step: dict) -> None:
         if step["local_ops"]:
-            self._passes += self.backend.apply_ops(step["local_ops"]) or 0
+            ops, self._pending = self._pending + list(step["local_ops"]), []
+            self._passes += self.backend.apply_ops(ops) or 0
         ops = step["nonlocal_ops"]
         i = 0
         while i < len(ops):
@@ -356,6 +377,7 @@ class DistributedEngine:
             for i, g in enumerate(glo):
                 peer = (peer & ~(1 << (g - self.k))) | (((d >> i) & 1) << (g - self.k))
             peers.append((d, peer))
+        self._flush_local()
         pieces = self._relayout_pieces(self.k - m)
         part = slab // pieces
         timer = self._comm_timer(send)
@@ -404,11 +426,11 @@ class DistributedEngine:
             elif a_glob:
                 row = d[self._rank_bit(qa)]
                 if not (row[0] == 1 and row[1] == 1):
-                    self.backend.apply_ops([([qb], np.diag(row))])
+                    self._queue_local(([qb], np.diag(row)))
             else:
                 col = d[:, self._rank_bit(qb)]
                 if not (col[0] == 1 and col[1] == 1):
-                    self.backend.apply_ops([([qa], np.diag(col))])
+                    self._queue_local(([qa], np.diag(col)))
             return
         V = _controlled_on_first(U)
         ctrl, tgt = qa, qb
@@ -418,7 +440,7 @@ class DistributedEngine:
         if V is not None and ctrl >= k:               # global control: conditional 1q gate
             if self._rank_bit(ctrl):
                 if tgt < k:
-                    self.backend.apply_ops([([tgt], V)])
+                    self._queue_local(([tgt], V))
                 else:
                     self.apply_nonlocal([tgt], V)
             return
@@ -436,7 +458,7 @@ class DistributedEngine:
 
     def _scale(self, f) -> None:
         if self.k > 0:
-            self.backend.apply_ops([([0], f * _I2)])
+            self._queue_local(([0], f * _I2))
         else:
             self._scale_single(f)
 
@@ -447,9 +469,11 @@ class DistributedEngine:
 
     def _exchange_full(self, peer: int) -> None:
         """Partner's whole shard into buf1 (apply_*_pair needs both chunks)."""
+        self._flush_local()
         self._exchange([(peer, self.backend.tensor("state"), self.backend.tensor("buf1"))])
 
     def _quad(self, qa: int, qb: int, U) -> None:
+        self._flush_local()
         ba, bb = self._rank_bit(qa), self._rank_bit(qb)
         me = 2 * ba + bb
         names = [None] * 4
@@ -469,6 +493,7 @@ class DistributedEngine:
 
     # ---- synchronisation / measurement ------------------------------------------------------------
     def barrier(self) -> None:
+        self._flush_local()
         self.backend.sync()
         self.dist.barrier()
 
@@ -489,6 +514,7 @@ class DistributedEngine:
     def closed_form_error(self, kind: str) -> float:
         """max over ALL 2^n amplitudes of |amp - closed form| ("ghz" / "ghz_qft"),
         evaluated on every shard in its current (staged) layout and max-reduced over ranks."""
+        self._flush_local()
         local = self.backend.closed_form_error(kind, self.n, self.rank << self.k, self.l2p)
         return self.max_over_ranks(local)
 
