@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Randomised GPU-vs-oracle stress (not part of the test suite): fused and per-gate op lists of
-every gate kind on n = 1..20 qubits, chunked runs with random chunk sizes, staged/unstaged.
-    python tools/stress_gpu.py [seconds]"""
+"""Randomised GPU-vs-oracle stress: fused and per-gate op lists of every gate kind on n = 1..20
+qubits, chunked runs with random chunk sizes, staged/unstaged.  A script, not collected by pytest;
+it lives under tests/ because only test code may use oracle/.
+    python tests/stress_gpu.py [seconds]"""
 import sys
 import time
 from pathlib import Path
