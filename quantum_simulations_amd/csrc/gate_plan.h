@@ -37,8 +37,6 @@ struct Tuning {
   int tile_merge_diag = 1;   // merge phase gates that share their predicate (OPC_DIAGR)
   int debug_skip_gates = 0;  // QSIM_DEBUG_SKIP_GATES=1: tile passes move data but apply nothing (WRONG results)
   int debug_stats = 0;       // QSIM_DEBUG_STATS=1: print gates / groups per pass to stderr
-  int tile_persistent = 0;   // resident grid + next-tile prefetch
-  int tile_wgs_per_cu = 8;   // upper bound for the persistent grid (the occupancy query decides)
   int num_cus = 256;
   // States up to this size stay in the 256 MiB Infinity Cache between launches when accessed with
   // the default cache policy (tools/mall_probe.hip: 8.5-8.8 TB/s r+w for a 128-256 MiB region vs
@@ -47,8 +45,6 @@ struct Tuning {
   Tuning() {
     if (const char* e = getenv("QSIM_MALL_BYTES")) mall_bytes = strtoull(e, nullptr, 10);
     if (const char* e = getenv("QSIM_DEBUG_STATS")) debug_stats = atoi(e);
-    if (const char* e = getenv("QSIM_TILE_PERSIST")) tile_persistent = atoi(e);
-    if (const char* e = getenv("QSIM_TILE_WGS")) tile_wgs_per_cu = std::max(1, atoi(e));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, 0) == hipSuccess && prop.multiProcessorCount > 0)
       num_cus = prop.multiProcessorCount;

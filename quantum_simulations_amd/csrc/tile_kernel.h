@@ -221,11 +221,10 @@ constexpr int tile_waves(int T) {
   return (160 * 1024) / ((1 << T) * 16) > 4 ? 4 : (160 * 1024) / ((1 << T) * 16);
 }
 
-// PERSIST: a resident grid walks tiles b, b + gridDim.x, ...; the global loads of the next tile are
-// issued right after the current tile has been written to LDS, so they are in flight during the
-// whole gate phase (software pipelining across tiles).
-template <int T, bool PERSIST, bool NT>
-__global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const TileArgs a, const unsigned ntiles) {
+// One workgroup per tile (a resident grid that prefetched the next tile into registers during the
+// gate phase was measured twice and was never faster: 163 VGPRs -> 3 workgroups per CU).
+template <int T, bool NT>
+__global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const TileArgs a) {
   constexpr int N = 1 << T;
   constexpr int LOW = kTileLow;
   constexpr int NH = T - LOW;                         // tile high bits
@@ -258,23 +257,15 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
     for (int i = TB - LOW; i < NH; ++i) o |= (u64)((j >> (i - (TB - LOW))) & 1) << a.h[i];
     return o;
   };
-  unsigned tile = blockIdx.x;
-  u64 base = tile_base(tile);
-  double2 v[PER];
+  const u64 base = tile_base(blockIdx.x);
+  {
+    double2 v[PER];
 #pragma unroll
-  for (int j = 0; j < PER; ++j) if (elem_ok) v[j] = ld_amp<NT>(a.amp + base + off_tid + off_j(j));
-  for (;;) {
+    for (int j = 0; j < PER; ++j) if (elem_ok) v[j] = ld_amp<NT>(a.amp + base + off_tid + off_j(j));
 #pragma unroll
-  for (int j = 0; j < PER; ++j) if (elem_ok) lds[lds_slot(tid + BLOCK * j)] = v[j];
-  __syncthreads();
-  const unsigned next = tile + gridDim.x;
-  const bool has_next = PERSIST && next < ntiles;
-  u64 next_base = 0;
-  if (PERSIST && has_next) {
-    next_base = tile_base(next);
-#pragma unroll
-    for (int j = 0; j < PER; ++j) if (elem_ok) v[j] = ld_amp<NT>(a.amp + next_base + off_tid + off_j(j));
+    for (int j = 0; j < PER; ++j) if (elem_ok) lds[lds_slot(tid + BLOCK * j)] = v[j];
   }
+  __syncthreads();
 
   const bool live = NBLK == BLOCK || tid < NBLK;
   int gi = 0;
@@ -367,8 +358,4 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
 #pragma unroll
     for (int j = 0; j < PER; ++j) if (elem_ok) st_amp<NT>(a.amp + base + off_tid + off_j(j), w[j]);
   }
-  if (!PERSIST || !has_next) break;
-  tile = next;
-  base = next_base;
-  }  // tile loop (each thread re-writes only the LDS slots it just read: no barrier needed)
 }

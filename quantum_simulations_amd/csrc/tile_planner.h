@@ -92,22 +92,10 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   } else {
   const u64 ntiles = 1ull << (c->k - T);
   ProfileScope prof(6, alg_bytes, stream, 32.0 * (double)amps(c));
-  if (tuning().tile_persistent) {
-    static int resident = 0;            // workgroups per CU that registers and LDS admit
-    if (!resident) {
-      int n = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile<T, true, true>, kTileThreads, 0) != hipSuccess || n < 1) n = 1;
-      resident = n;
-    }
-    const int per_cu = std::max(1, std::min(tuning().tile_wgs_per_cu, resident));
-    const u64 blocks = std::min<u64>(ntiles, (u64)tuning().num_cus * per_cu);
-    hipLaunchKernelGGL((k_tile<T, true, true>), dim3((unsigned)blocks), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
-  } else {
-    bool nt = c->span_bytes > tuning().mall_bytes;
-    if (tuning().force_nt >= 0) nt = tuning().force_nt != 0;
-    if (nt) hipLaunchKernelGGL((k_tile<T, false, true>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
-    else hipLaunchKernelGGL((k_tile<T, false, false>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a, (unsigned)ntiles);
-  }
+  bool nt = c->span_bytes > tuning().mall_bytes;       // cache policy by state size (gate_plan.h)
+  if (tuning().force_nt >= 0) nt = tuning().force_nt != 0;
+  if (nt) hipLaunchKernelGGL((k_tile<T, true>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a);
+  else hipLaunchKernelGGL((k_tile<T, false>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a);
   prof.done(stream);
   HIP_TRY(hipGetLastError());
   return QSIM_OK;
