@@ -37,7 +37,6 @@ struct Tuning {
   int tile_merge_diag = 1;   // merge phase gates that share their predicate (OPC_DIAGR)
   int debug_skip_gates = 0;  // QSIM_DEBUG_SKIP_GATES=1: tile passes move data but apply nothing (WRONG results)
   int debug_stats = 0;       // QSIM_DEBUG_STATS=1: print gates / groups per pass to stderr
-  int num_cus = 256;
   // States up to this size stay in the 256 MiB Infinity Cache between launches when accessed with
   // the default cache policy (tools/mall_probe.hip: 8.5-8.8 TB/s r+w for a 128-256 MiB region vs
   // 5.5 streaming); the NT policy bypasses it (6.0-6.2 at every size), so NT is for larger states.
@@ -45,9 +44,6 @@ struct Tuning {
   Tuning() {
     if (const char* e = getenv("QSIM_MALL_BYTES")) mall_bytes = strtoull(e, nullptr, 10);
     if (const char* e = getenv("QSIM_DEBUG_STATS")) debug_stats = atoi(e);
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, 0) == hipSuccess && prop.multiProcessorCount > 0)
-      num_cus = prop.multiProcessorCount;
     if (const char* e = getenv("QSIM_SWZ_CUT")) swz_cut = atoi(e);
     if (const char* e = getenv("QSIM_NT")) force_nt = atoi(e);
     if (const char* e = getenv("QSIM_ITEMS")) items = atoi(e);

@@ -20,9 +20,6 @@
 #ifndef QSIM_TILE_LOW
 #define QSIM_TILE_LOW 3
 #endif
-#ifndef QSIM_TILE_SWZ
-#define QSIM_TILE_SWZ 0
-#endif
 constexpr int kTileLow = QSIM_TILE_LOW;
 #ifndef QSIM_TILE_BITS_MAX
 #define QSIM_TILE_BITS_MAX 11
