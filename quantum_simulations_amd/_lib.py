@@ -51,6 +51,7 @@ SIGNATURES = {
     "qsim_apply_2q": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "qsim_apply_ops": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "qsim_apply_ops_unfused": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "qsim_plan_ops": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, C.c_uint64, _P]),
     "qsim_last_pass_count": (C.c_int, [_P]),
     "qsim_apply_1q_pair": (C.c_int, [_P, _P, _P]),
     "qsim_apply_2q_pair_qa_local": (C.c_int, [_P, _P, C.c_int, _P]),

@@ -279,6 +279,41 @@ int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* q
 
 int qsim_last_pass_count(const qsim_chunk* c) { return c ? c->last_passes : -1; }
 
+static_assert(sizeof(TileArgs) == QSIM_PASS_IMAGE_BYTES, "pass image = the kernel-argument block of k_tile");
+
+int qsim_plan_ops(int n_local_qubits, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,
+                  void* out, uint64_t out_capacity_bytes, int32_t* n_passes) {
+  if (!n_passes) return fail(QSIM_ERR_INVALID, "qsim_plan_ops: n_passes is null");
+  if (n_local_qubits < kTileMinChunk || n_local_qubits > 40)
+    return fail(QSIM_ERR_INVALID, "qsim_plan_ops: fused passes need %d..40 local qubits", kTileMinChunk);
+  if (n_ops < 0 || (n_ops && (!nq || !qubits || !mats))) return fail(QSIM_ERR_INVALID, "bad op list");
+  std::vector<FusedOp> ops;
+  for (int i = 0; i < n_ops; ++i) {
+    if (nq[i] != 1 && nq[i] != 2) return fail(QSIM_ERR_INVALID, "op %d: arity %d", i, nq[i]);
+    for (int j = 0; j < nq[i]; ++j)
+      if (qubits[2 * i + j] < 0 || qubits[2 * i + j] >= n_local_qubits)
+        return fail(QSIM_ERR_NONLOCAL, "qubit %d >= log2(chunk_size)=%d: non-local gate requires layout/collect step",
+                    qubits[2 * i + j], n_local_qubits);
+    if (nq[i] == 2 && qubits[2 * i] == qubits[2 * i + 1]) return fail(QSIM_ERR_INVALID, "op %d: repeated qubit", i);
+    FusedOp o;
+    if (classify_op(nq[i], qubits + 2 * i, mats + 32 * (size_t)i, &o)) ops.push_back(o);
+  }
+  int passes = 0;
+  char* dst = (char*)out;
+  uint64_t used = 0;
+  int rc = plan_fused(n_local_qubits, ops, &passes, [&](TileArgs& a, int T, double) {
+    if (dst) {
+      if (used + sizeof(TileArgs) > out_capacity_bytes) return fail(QSIM_ERR_INVALID, "qsim_plan_ops: output buffer too small");
+      a.pad = T;                                   // the image of a pass carries its tile size here
+      std::memcpy(dst + used, &a, sizeof a);
+    }
+    used += sizeof(TileArgs);
+    return (int)QSIM_OK;
+  });
+  *n_passes = passes;
+  return rc;
+}
+
 int qsim_apply_1q_pair(qsim_chunk* c0, qsim_chunk* c1, const double U[8]) {
   qsim_chunk* cs[2] = {c0, c1};
   int rc = check_group(cs, 2, "qsim_apply_1q_pair");

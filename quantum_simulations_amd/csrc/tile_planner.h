@@ -299,8 +299,10 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
 // Greedy pass builder.  Ops are taken in list order; an op that does not fit the current tile
 // blocks its qubits, and later ops on blocked qubits wait for the next pass, so any two ops
 // sharing a qubit keep their order (ops on disjoint qubits commute).
-static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_passes) {
-  const int k = c->k;
+// `sink(args, T, algorithmic_bytes)` receives every planned pass: the launcher on the device path,
+// a serialiser in qsim_plan_ops (the planner itself never touches the GPU).
+template <class Sink>
+static int plan_fused(int k, const std::vector<FusedOp>& ops, int* n_passes, Sink&& sink) {
   const Tuning& tune = tuning();
   const int T = k < kTileBitsMax ? k : kTileBitsMax;
   const int low = kTileLow;
@@ -340,7 +342,6 @@ static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_pass
     if (tune.debug_skip_gates == 3) for (int j = 0; j < cap; ++j) high[j] = k - cap + j; // far-strided tiles
     TileArgs a;
     std::memset(&a, 0, sizeof a);
-    a.amp = c->amp;
     for (size_t j = 0; j < high.size(); ++j) a.h[j] = (uint8_t)high[j];
     std::vector<char> emitted(members.size(), 0);
     emit_groups(ops, members, high, T, &a, &emitted);
@@ -350,7 +351,7 @@ static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_pass
       if (emitted[mi]) {
         const FusedOp& o = ops[members[mi]];
         const int halvings = o.kind == TG_PHASE ? o.nbits : (o.control >= 0 ? 1 : o.halvings);
-        alg_bytes += 32.0 * (double)(amps(c) >> halvings);
+        alg_bytes += 32.0 * (double)((1ull << k) >> halvings);
         done[members[mi]] = 1; --remaining; ++n_emitted;
       }
     if (!n_emitted) return fail(QSIM_ERR_INVALID, "internal: fused planner emitted nothing");
@@ -360,9 +361,16 @@ static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_pass
       std::fprintf(stderr, "[qsim] pass %d: %zu gates, %d groups, %d entries\n", *n_passes, n_emitted, groups, a.ngates);
     }
     if (tune.debug_skip_gates) a.ngates = 0;       // profiling aid: load -> LDS -> store only
-    int rc = launch_tile_any(a, T, c, c->stream, alg_bytes);
+    int rc = sink(a, T, alg_bytes);
     if (rc) return rc;
     ++*n_passes;
   }
   return QSIM_OK;
+}
+
+static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_passes) {
+  return plan_fused(c->k, ops, n_passes, [&](TileArgs& a, int T, double alg_bytes) {
+    a.amp = c->amp;
+    return launch_tile_any(a, T, c, c->stream, alg_bytes);
+  });
 }

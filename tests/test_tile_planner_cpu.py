@@ -1,0 +1,82 @@
+"""The host planner of the fused passes on the CPU: `qsim_plan_ops` plans an op list without a
+device, tests/tile_interpreter.py executes the emitted pass images on a numpy state following the
+opcode table, and the result must equal the dense oracle.  Covers pass building, register
+groups, opcode / mask encoding, merged phase runs (OPC_DIAGR) and their ordering, argument budgets."""
+import numpy as np
+import pytest
+
+from oracle import dense_oracle as orc
+from tests import tile_interpreter as ti
+from tests.test_gpu_kernels import _rand_state, _random_ops
+
+
+@pytest.mark.parametrize("n", [8, 9, 11, 12, 14])
+def test_planned_passes_equal_oracle_random_ops(n):
+    for seed in range(4):
+        ops = _random_ops(n, 120, 70 * n + seed)
+        psi = _rand_state(n, 300 + seed)
+        want = psi.copy()
+        orc.apply_ops(want, ops)
+        images = ti.plan(n, ops)
+        assert 1 <= len(images) <= len(ops)
+        ti.run(psi, images)
+        np.testing.assert_allclose(psi, want, rtol=0, atol=1e-12, err_msg=f"n={n} seed={seed}")
+
+
+def test_phase_runs_are_merged_and_ordered():
+    """QFT: the CR(k, a), CR(k, b), CR(k, c) of a register group share one descriptor, and every
+    merged run is written out before the next Hadamard on one of its bits."""
+    from quantum_simulations_amd.circuit.io import validate_circuit_dict
+    from quantum_simulations_amd.circuits import generate_ghz_qft
+    from quantum_simulations_amd.runner.engine import gate_ops
+    n = 13
+    cd = validate_circuit_dict(generate_ghz_qft(n))
+    ops = gate_ops(cd)
+    images = ti.plan(n, ops)
+    psi = np.zeros(1 << n, dtype=np.complex128)
+    psi[0] = 1
+    descriptors = ti.run(psi, images)
+    np.testing.assert_allclose(psi, orc.simulate(cd), rtol=0, atol=1e-12)
+    assert descriptors < len(ops)                                   # merging happened
+    assert any(int(g["opcode"]) >= ti.OPC["DIAGR"] and int(g["opcode"]) != ti.OPC["GROUP"]
+               for img in images for g in img["g"][:int(img["ngates"])])
+
+
+def test_bench_workload_pass_count():
+    """The 28-qubit depth-40 bench circuit plans into 24 passes; planning needs
+    no device and no state."""
+    from quantum_simulations_amd.circuit.fusion import batch_levels
+    from quantum_simulations_amd.circuit.io import levelize, validate_circuit_dict
+    from quantum_simulations_amd.circuits import random_1q_cx_circuit
+    cd = validate_circuit_dict(random_1q_cx_circuit(28, depth=40))
+    total = sum(len(ti.plan(28, p["local_ops"])) for p in batch_levels(levelize(cd), 28))
+    assert total == 24
+
+
+def test_argument_budget_is_respected():
+    """Many dense 2q gates (16 pool entries each): passes are cut by the matrix-pool budget and
+    every image stays within the descriptor / pool capacity."""
+    n = 10
+    rng = np.random.default_rng(8)
+    ops = []
+    for i in range(60):
+        qa, qb = (int(x) for x in rng.choice(n, size=2, replace=False))
+        z = rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4))
+        ops.append(([qa, qb], np.linalg.qr(z)[0]))
+    images = ti.plan(n, ops)
+    assert len(images) >= 60 * 16 // (ti.MAX_MAT - 3)
+    psi = _rand_state(n, 5)
+    want = psi.copy()
+    orc.apply_ops(want, ops)
+    ti.run(psi, images)
+    np.testing.assert_allclose(psi, want, rtol=0, atol=1e-12)
+    for img in images:
+        assert 0 < int(img["ngates"]) <= ti.MAX_GATES
+
+
+def test_plan_ops_rejects_bad_input():
+    H = orc.gate_matrix("H")
+    with pytest.raises(NotImplementedError, match="non-local"):
+        ti.plan(9, [([9], H)])
+    with pytest.raises(ValueError):
+        ti.plan(4, [([0], H)])                 # below the fused-pass minimum
