@@ -296,9 +296,17 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
   }
 }
 
-// Greedy pass builder.  Ops are taken in list order; an op that does not fit the current tile
-// blocks its qubits, and later ops on blocked qubits wait for the next pass, so any two ops
-// sharing a qubit keep their order (ops on disjoint qubits commute).
+// Pass builder.  Ops are taken in list order; an op whose non-diagonal targets are not all tile
+// bits blocks its qubits, and later ops on blocked qubits wait for the next pass, so any two ops
+// sharing a qubit keep their order (ops on disjoint qubits commute).  WHICH qubits become the tile's
+// high bits decides how many ops a pass holds:
+//   * first come: an op that still fits claims the bits it needs (the only rule up to r01e);
+//   * look-ahead: starting from the first 0, 2, 4, 6 of those bits, add the bit that lets the pass
+//     hold the most ops, one at a time;
+// the candidate that holds the most ops wins (first come on ties).  On the 28-qubit bench circuit
+// this needs 20-21 passes instead of 24 (tests/test_tile_planner_cpu.py); the search costs about
+// 0.3 ms per pass on the host, hidden behind the previous pass on the device for large states and
+// switched off for small ones (QSIM_PLAN_LOOKAHEAD = 0 / 1 forces).
 // `sink(args, T, algorithmic_bytes)` receives every planned pass: the launcher on the device path,
 // a serialiser in qsim_plan_ops (the planner itself never touches the GPU).
 template <class Sink>
@@ -307,32 +315,79 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops, int* n_passes, Sin
   const int T = k < kTileBitsMax ? k : kTileBitsMax;
   const int low = kTileLow;
   const int cap = T - low;                      // tile high-bit capacity
-  std::vector<char> done(ops.size(), 0);
-  size_t remaining = ops.size();
+  const size_t n_ops = ops.size();
+  std::vector<char> done(n_ops, 0);
+  std::vector<u64> qm(n_ops), need(n_ops);     // all qubits of an op; its target bits above the low bits
+  for (size_t i = 0; i < n_ops; ++i) {
+    qm[i] = op_qmask(ops[i]);
+    need[i] = 0;
+    for (int t = 0; t < ops[i].ntargets; ++t)
+      if (ops[i].target[t] >= low) need[i] |= 1ull << ops[i].target[t];
+  }
+  const u64 all_qubits = k >= 64 ? ~0ull : ((1ull << k) - 1);
+  const bool lookahead = tune.plan_lookahead >= 0 ? tune.plan_lookahead != 0 : k >= 24;
+  size_t remaining = n_ops;
   size_t first = 0;
   *n_passes = 0;
-  while (remaining) {
-    std::vector<int> high;                      // chosen high bits
-    std::vector<size_t> members;
+  // ops a pass with the given high bits would hold (optionally listed)
+  auto holds = [&](u64 tile_mask, std::vector<size_t>* out) -> int {
     u64 blocked = 0;
-    while (first < ops.size() && done[first]) ++first;
-    for (size_t i = first; i < ops.size() && (int)members.size() < tune.max_gates_per_pass; ++i) {
+    int count = 0;
+    for (size_t i = first; i < n_ops && count < tune.max_gates_per_pass; ++i) {
       if (done[i]) continue;
-      const FusedOp& o = ops[i];
-      const u64 qmask = op_qmask(o);
-      bool ok = !(blocked & qmask);
-      int need[2], nneed = 0;
-      if (ok) {
-        for (int t = 0; t < o.ntargets; ++t) {
-          const int b = o.target[t];
-          if (b >= low && std::find(high.begin(), high.end(), b) == high.end()) need[nneed++] = b;
-        }
-        if ((int)high.size() + nneed > cap) ok = false;
+      if ((blocked & qm[i]) || (need[i] & ~tile_mask)) {
+        blocked |= qm[i];
+        if (blocked == all_qubits) break;
+        continue;
       }
-      if (!ok) { blocked |= qmask; continue; }
-      for (int t = 0; t < nneed; ++t) high.push_back(need[t]);
-      members.push_back(i);
+      ++count;
+      if (out) out->push_back(i);
     }
+    return count;
+  };
+  while (remaining) {
+    while (first < n_ops && done[first]) ++first;
+    // candidate 0: first come
+    std::vector<int> claimed;                   // high bits in the order they were claimed
+    {
+      u64 blocked = 0, mask = 0;
+      int count = 0;
+      for (size_t i = first; i < n_ops && count < tune.max_gates_per_pass; ++i) {
+        if (done[i]) continue;
+        bool ok = !(blocked & qm[i]);
+        const u64 extra = need[i] & ~mask;
+        if (ok && (int)claimed.size() + __builtin_popcountll(extra) > cap) ok = false;
+        if (!ok) { blocked |= qm[i]; if (blocked == all_qubits) break; continue; }
+        for (u64 e = extra; e; e &= e - 1) claimed.push_back(__builtin_ctzll(e));
+        mask |= extra;
+        ++count;
+      }
+    }
+    auto mask_of = [](const std::vector<int>& bits, size_t n) { u64 m = 0; for (size_t i = 0; i < n && i < bits.size(); ++i) m |= 1ull << bits[i]; return m; };
+    u64 best_mask = mask_of(claimed, claimed.size());
+    int best_count = holds(best_mask, nullptr);
+    if (lookahead && k - low > cap) {
+      for (size_t seed = 0; seed <= 6 && seed <= claimed.size(); seed += 2) {
+        u64 mask = mask_of(claimed, seed);
+        int count = 0;
+        while (__builtin_popcountll(mask) < cap) {
+          int pick = -1, pick_count = -1;
+          for (int b = low; b < k; ++b) {
+            if ((mask >> b) & 1) continue;
+            const int c = holds(mask | (1ull << b), nullptr);
+            if (c > pick_count) { pick_count = c; pick = b; }
+          }
+          if (pick < 0) break;
+          mask |= 1ull << pick;
+          count = pick_count;
+        }
+        if (count > best_count) { best_count = count; best_mask = mask; }
+      }
+    }
+    std::vector<int> high;                      // chosen high bits
+    for (int b = low; b < k; ++b) if ((best_mask >> b) & 1) high.push_back(b);
+    std::vector<size_t> members;
+    holds(best_mask, &members);
     if (members.empty()) return fail(QSIM_ERR_INVALID, "internal: fused planner made no progress");
     // fill the tile with the lowest unused bits so it always has T bits
     for (int b = low; (int)high.size() < cap && b < k; ++b)
@@ -340,6 +395,13 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops, int* n_passes, Sin
     std::sort(high.begin(), high.end());
     if (tune.debug_skip_gates == 2) for (int j = 0; j < cap; ++j) high[j] = low + j;   // contiguous tiles (floor probe)
     if (tune.debug_skip_gates == 3) for (int j = 0; j < cap; ++j) high[j] = k - cap + j; // far-strided tiles
+    if (tune.debug_skip_gates == 4) {   // tile bits from QSIM_DEBUG_TILE_BITS="b0,b1,..." (memory-pattern probe)
+      if (const char* e = getenv("QSIM_DEBUG_TILE_BITS")) {
+        std::vector<int> bits;
+        for (const char* p = e; *p;) { bits.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
+        if ((int)bits.size() == cap) { high = bits; std::sort(high.begin(), high.end()); }
+      }
+    }
     TileArgs a;
     std::memset(&a, 0, sizeof a);
     for (size_t j = 0; j < high.size(); ++j) a.h[j] = (uint8_t)high[j];
@@ -371,6 +433,22 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops, int* n_passes, Sin
 static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_passes) {
   return plan_fused(c->k, ops, n_passes, [&](TileArgs& a, int T, double alg_bytes) {
     a.amp = c->amp;
-    return launch_tile_any(a, T, c, c->stream, alg_bytes);
+    if (tuning().debug_stats < 2) return launch_tile_any(a, T, c, c->stream, alg_bytes);
+    // QSIM_DEBUG_STATS=2: time every pass synchronously and print its shape (profiling aid)
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, c->stream);
+    const int rc = launch_tile_any(a, T, c, c->stream, alg_bytes);
+    (void)hipEventRecord(e1, c->stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    int groups = 0, gates = 0;
+    for (int i = 0; i < a.ngates; ++i) (get_gate(&a, i).opcode == OPC_GROUP ? groups : gates)++;
+    std::fprintf(stderr, "[qsim] timed pass: %.3f ms, %d descriptors, %d groups, high bits", ms, gates, groups);
+    for (int j = 0; j < T - kTileLow; ++j) std::fprintf(stderr, " %d", a.h[j]);
+    std::fprintf(stderr, "\n");
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
   });
 }

@@ -2,6 +2,10 @@
 device, tests/tile_interpreter.py executes the emitted pass images on a numpy state following the
 opcode table, and the result must equal the dense oracle.  Covers pass building, register
 groups, opcode / mask encoding, merged phase runs (OPC_DIAGR) and their ordering, argument budgets."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -43,14 +47,14 @@ def test_phase_runs_are_merged_and_ordered():
 
 
 def test_bench_workload_pass_count():
-    """The 28-qubit depth-40 bench circuit plans into 24 passes; planning needs
-    no device and no state."""
+    """The 28-qubit depth-40 bench circuit plans into 19 passes with the tile-bit look-ahead (24 with
+    the first-come rule alone); planning needs no device and no state."""
     from quantum_simulations_amd.circuit.fusion import batch_levels
     from quantum_simulations_amd.circuit.io import levelize, validate_circuit_dict
     from quantum_simulations_amd.circuits import random_1q_cx_circuit
     cd = validate_circuit_dict(random_1q_cx_circuit(28, depth=40))
     total = sum(len(ti.plan(28, p["local_ops"])) for p in batch_levels(levelize(cd), 28))
-    assert total == 24
+    assert total == (24 if os.environ.get("QSIM_PLAN_LOOKAHEAD") == "0" else 19)
 
 
 def test_argument_budget_is_respected():
@@ -80,3 +84,17 @@ def test_plan_ops_rejects_bad_input():
         ti.plan(9, [([9], H)])
     with pytest.raises(ValueError):
         ti.plan(4, [([0], H)])                 # below the fused-pass minimum
+
+
+def test_lookahead_planner_on_small_states():
+    """The look-ahead is on by default only for states of >= 24 qubits; the knob is read once per
+    process, so this module is re-run in ONE child process with it forced on (and once forced off)
+    to execute the planned passes of the small cases above under both rules."""
+    if os.environ.get("QSIM_PLANNER_CHILD"):
+        pytest.skip("already inside the child run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for setting in ("1", "0"):
+        env = dict(os.environ, QSIM_PLAN_LOOKAHEAD=setting, QSIM_PLANNER_CHILD="1", PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", __file__],
+                             cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, f"QSIM_PLAN_LOOKAHEAD={setting}\n" + out.stdout[-3000:] + out.stderr[-2000:]
