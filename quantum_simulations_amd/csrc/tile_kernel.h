@@ -31,7 +31,8 @@ constexpr int kGroupBits = 3;
 #endif
 constexpr int kTileThreads = QSIM_TILE_THREADS;
 constexpr int kTileThreadBits = kTileThreads == 64 ? 6 : kTileThreads == 128 ? 7 : kTileThreads == 256 ? 8 : kTileThreads == 512 ? 9 : 10;
-constexpr int kTileMaxGates = 144;     // entries incl. group headers  (2304 B of kernel arguments)
+constexpr int kTileGateSlots = 144;    // descriptor array                  (2304 B of kernel arguments)
+constexpr int kTileMaxGates = 143;     // usable entries incl. group headers: the device reads one entry ahead
 constexpr int kTileMaxMat = 104;       // complex matrix pool          (1664 B)
 
 enum : uint8_t {
@@ -77,7 +78,7 @@ struct TileArgs {
   int ngates;
   int pad;
   uint8_t h[16];           // ascending absolute positions of the tile's high bits
-  u32x4 g[kTileMaxGates];  // TileGate images
+  u32x4 g[kTileGateSlots]; // TileGate images
   double2 mat[kTileMaxMat];
 };
 static_assert(sizeof(TileArgs) <= 4096, "kernel arguments must fit 4 KiB");
@@ -265,10 +266,17 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
   __syncthreads();
 
   const bool live = NBLK == BLOCK || tid < NBLK;
+  // Descriptors are read ONE ENTRY AHEAD: a gate's chain was s_load descriptor -> wait -> s_load
+  // matrix -> wait -> dispatch, and above ~32 gates a pass is bound by that per-gate latency
+  // (0.03 ms per descriptor at 28 qubits); with the next descriptor already in flight the matrix
+  // load and the descriptor load of the following gate share one wait behind the dispatch.
   int gi = 0;
+  u32x4 nxt = a.g[0];
   while (gi < a.ngates) {
     gi = __builtin_amdgcn_readfirstlane(gi);          // keep the descriptor reads scalar
-    const u32x4 hd = a.g[gi++];                       // group header: opcode | count << 8 | bits << 16
+    const u32x4 hd = nxt;                             // group header: opcode | count << 8 | bits << 16
+    nxt = a.g[(unsigned)(gi + 1) & 0xFF];
+    ++gi;
     const unsigned hb = hd.x >> 16;
     const int s0 = hb & 15, s1 = (hb >> 4) & 15, s2 = (hb >> 8) & 15;
     const int ge = gi + ((hd.x >> 8) & 0xFF);
@@ -287,7 +295,8 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
     // descriptor (unsigned index), and the lane predicate evaluated only for gates that have one.
     for (unsigned q0 = (unsigned)gi, qe = (unsigned)ge; q0 != qe; ++q0) {
       const unsigned q = __builtin_amdgcn_readfirstlane(q0);
-      const u32x4 g = a.g[q & 0xFF];                  // one s_load_dwordx4 (index the kernarg arrays directly:
+      const u32x4 g = nxt;                            // loaded one iteration ago
+      nxt = a.g[(q + 1) & 0xFF];                      // one s_load_dwordx4 (index the kernarg arrays directly:
                                                       // a pointer formed into them turns the loads into vector loads)
       const int mq = g.y & 0xFFFF;                    // (known-small indices fold into the load's offset); pool keeps 3 spare entries
       const double2 u00 = a.mat[mq], u01 = a.mat[mq + 1], u10 = a.mat[mq + 2], u11 = a.mat[mq + 3];

@@ -75,7 +75,7 @@ def test_argument_budget_is_respected():
     ti.run(psi, images)
     np.testing.assert_allclose(psi, want, rtol=0, atol=1e-12)
     for img in images:
-        assert 0 < int(img["ngates"]) <= ti.MAX_GATES
+        assert 0 < int(img["ngates"]) < ti.MAX_GATES
 
 
 def test_plan_ops_rejects_bad_input():

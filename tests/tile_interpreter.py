@@ -15,7 +15,7 @@ from quantum_simulations_amd import _lib
 from quantum_simulations_amd.kernel.device import pack_ops
 
 IMAGE_BYTES = 4000
-MAX_GATES, MAX_MAT = 144, 104
+MAX_GATES, MAX_MAT = 144, 104      # descriptor slots (143 usable: the device reads one entry ahead), pool entries
 OPC = dict(DENSE1=1, SWAP1=10, ANTI1=19, PHASE=28, DENSE2=36, REAL1=45, YLIKE1=54, PHASE_NEG=63,
            PHASE_I=71, PHASE_NI=79, DIAGR=87, GROUP=0xFE)
 _GATE = np.dtype([("opcode", "u1"), ("count", "u1"), ("blk_mask", "<u2"), ("mat", "<u2"), ("pad", "<u2"),
