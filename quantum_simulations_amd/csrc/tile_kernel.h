@@ -42,7 +42,7 @@ enum : uint8_t {
   OPC_ANTI1 = 19,     // +variant: a' = u01 b, b' = u10 a                     (pool: 4)
   OPC_PHASE = 28,     // +register mask 0..7: x *= m[0]     T, R, CR          (pool: 1)
   OPC_DENSE2 = 36,    // +3*JA + JB: general 4x4, SWAP                        (pool: 16)
-  OPC_REAL1 = 45,     // +variant: 2x2 with real entries    H, RY, G          (pool: 4)
+  OPC_REAL1 = 45,     // +variant: 2x2 with real entries    H, RY, G          (pool: 2, packed)
   OPC_YLIKE1 = 54,    // +variant: [[0,-i],[i,0]]           Y, CY             (pool: 0)
   OPC_PHASE_NEG = 63, // +mask: x = -x                      Z, CZ             (pool: 0)
   OPC_PHASE_I = 71,   // +mask: x = i x                     S                 (pool: 0)
@@ -139,13 +139,14 @@ __device__ __forceinline__ unsigned lds_slot(unsigned t) { return t ^ ((t >> 4) 
 #endif
 #if defined(QSIM_PLAIN_ALL)
 #define QS_DR(A, B) { const double2 a_ = A, b_ = B;                                               \
-    A = make_double2(fma(u01.x, b_.x, u00.x * a_.x), fma(u01.x, b_.y, u00.x * a_.y));               \
-    B = make_double2(fma(u11.x, b_.x, u10.x * a_.x), fma(u11.x, b_.y, u10.x * a_.y)); }
+    A = make_double2(fma(u00.y, b_.x, u00.x * a_.x), fma(u00.y, b_.y, u00.x * a_.y));               \
+    B = make_double2(fma(u01.y, b_.x, u01.x * a_.x), fma(u01.y, b_.y, u01.x * a_.y)); }
 #else
+// real 2x2, packed by the host into two pool entries: u00 = (r00, r01), u01 = (r10, r11)
 #define QS_DR(A, B) {                                                                               \
-    const double tx_ = u00.x * A.x, ty_ = u00.x * A.y, sx_ = u10.x * A.x, sy_ = u10.x * A.y;        \
-    QS_IP_FMA(A.x, u01.x, B.x, tx_); QS_IP_FMA(A.y, u01.x, B.y, ty_);                               \
-    QS_IP_FMA(B.x, u11.x, B.x, sx_); QS_IP_FMA(B.y, u11.x, B.y, sy_); }
+    const double tx_ = u00.x * A.x, ty_ = u00.x * A.y, sx_ = u01.x * A.x, sy_ = u01.x * A.y;        \
+    QS_IP_FMA(A.x, u00.y, B.x, tx_); QS_IP_FMA(A.y, u00.y, B.y, ty_);                               \
+    QS_IP_FMA(B.x, u01.y, B.x, sx_); QS_IP_FMA(B.y, u01.y, B.y, sy_); }
 #endif
 #if defined(QSIM_PLAIN_PERM) || defined(QSIM_PLAIN_ALL)
 #define QS_YL(A, B) { const double2 a_ = A, b_ = B; A = make_double2(b_.y, -b_.x); B = make_double2(-a_.y, a_.x); }

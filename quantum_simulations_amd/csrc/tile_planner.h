@@ -130,7 +130,8 @@ static int pool_entries(const FusedOp& o) {
     case TG_PHASE: return (sp && (is(0, -1, 0) || is(0, 0, 1) || is(0, 0, -1))) ? 0 : 1;
     case TG_ANTI1: return (sp && is(1, 0, -1) && is(2, 0, 1)) ? 0 : 4;
     case TG_DENSE2: return 16;
-    default: return 4;
+    default:   // a real 2x2 (H, RY, G) packs its four entries into two: (u00, u01) and (u10, u11)
+      return (sp && o.kind == TG_DENSE1 && o.m[0].y == 0 && o.m[1].y == 0 && o.m[2].y == 0 && o.m[3].y == 0) ? 2 : 4;
   }
 }
 
@@ -287,7 +288,12 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
         for (int t = 0; t < o.ntargets; ++t) tmask |= 1u << reg_pos(tile_pos(o.target[t]));
         for (size_t i = open.size(); i-- > 0;) if (open[i].touched & tmask) flush(i);
       }
-      emit(g, o.m, std::min(pool_entries(o), o.nm));
+      if (g.opcode >= OPC_REAL1 && g.opcode < OPC_REAL1 + 9) {
+        const double2 packed[2] = {make_double2(o.m[0].x, o.m[1].x), make_double2(o.m[2].x, o.m[3].x)};
+        emit(g, packed, 2);
+      } else {
+        emit(g, o.m, std::min(pool_entries(o), o.nm));
+      }
     }
     while (!open.empty()) flush(0);
     hd.count = (uint8_t)n_emitted;
@@ -366,7 +372,12 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops, int* n_passes, Sin
     auto mask_of = [](const std::vector<int>& bits, size_t n) { u64 m = 0; for (size_t i = 0; i < n && i < bits.size(); ++i) m |= 1ull << bits[i]; return m; };
     u64 best_mask = mask_of(claimed, claimed.size());
     int best_count = holds(best_mask, nullptr);
-    if (lookahead && k - low > cap) {
+    // A pass is memory bound up to ~32 descriptors and pays ~0.03 ms for each one beyond that
+    // (tools/gate_cost_probe.py), so holding more than kSaturated ops buys nothing: a first-come
+    // pass that is already that full is kept (phase-heavy circuits: QFT).
+    constexpr int kSaturated = 64;
+    best_count = std::min(best_count, kSaturated);
+    if (lookahead && k - low > cap && best_count < kSaturated) {
       for (size_t seed = 0; seed <= 6 && seed <= claimed.size(); seed += 2) {
         u64 mask = mask_of(claimed, seed);
         int count = 0;
@@ -381,6 +392,7 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops, int* n_passes, Sin
           mask |= 1ull << pick;
           count = pick_count;
         }
+        count = std::min(count, kSaturated);
         if (count > best_count) { best_count = count; best_mask = mask; }
       }
     }

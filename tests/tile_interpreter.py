@@ -97,10 +97,10 @@ def run_pass(psi: np.ndarray, img) -> int:
                     U = np.array([[0, -1j], [1j, 0]])
                 elif fam == OPC["ANTI1"]:
                     U = np.array([[0, mat[m + 1]], [mat[m + 2], 0]])
+                elif fam == OPC["REAL1"]:       # packed: entry 0 = (r00, r01), entry 1 = (r10, r11)
+                    U = np.array([[mat[m].real, mat[m].imag], [mat[m + 1].real, mat[m + 1].imag]], dtype=complex)
                 else:
                     U = mat[m:m + 4].reshape(2, 2)
-                    if fam == OPC["REAL1"]:
-                        assert not np.any(U.imag)
                 _apply_1q(psi, idx, A[J], U, cond | (0 if ctrl is None else 1 << A[ctrl]))
             elif fam in (OPC["PHASE"], OPC["PHASE_NEG"], OPC["PHASE_I"], OPC["PHASE_NI"]):
                 f = {OPC["PHASE"]: mat[m], OPC["PHASE_NEG"]: -1, OPC["PHASE_I"]: 1j, OPC["PHASE_NI"]: -1j}[fam]
