@@ -98,3 +98,38 @@ def test_lookahead_planner_on_small_states():
         out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", __file__],
                              cwd=root, env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, f"QSIM_PLAN_LOOKAHEAD={setting}\n" + out.stdout[-3000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("n", [9, 12, 14])
+def test_merged_descriptors_keep_list_order(n):
+    """Merged phase runs (OPC_DIAGR) are written out late; a gate on one of their bits must still see
+    them in list order.  Circuits dense in
+    predicated phases (CR with few distinct controls), 1q phases and non-diagonal 1q gates on the
+    same few qubits, many seeds, against the oracle."""
+    for seed in range(12):
+        rng = np.random.default_rng(9000 + 31 * n + seed)
+        ctrls = [int(q) for q in rng.choice(n, size=3, replace=False)]
+        hot = [int(q) for q in rng.choice(n, size=4, replace=False)]
+        ops = []
+        for _ in range(200):
+            r = rng.random()
+            q = hot[int(rng.integers(4))] if rng.random() < 0.7 else int(rng.integers(n))
+            if r < 0.35:
+                c = ctrls[int(rng.integers(3))]
+                if c != q:
+                    ops.append(([c, q] if rng.random() < 0.5 else [q, c], orc.gate_matrix("CR", {"k": int(rng.integers(1, 7))})))
+            elif r < 0.60:
+                ops.append(([q], orc.gate_matrix(("T", "R", "S", "Z")[int(rng.integers(4))], {"k": int(rng.integers(1, 7))})))
+            elif r < 0.90:
+                ops.append(([q], orc.gate_matrix(("H", "RY", "X", "Y")[int(rng.integers(4))], {"theta": float(rng.uniform(0, 6))})))
+            else:
+                t = int(rng.integers(n))
+                if t != q:
+                    ops.append(([q, t], orc.gate_matrix("CNOT")))
+        psi = _rand_state(n, 40 + seed)
+        want = psi.copy()
+        orc.apply_ops(want, ops)
+        images = ti.plan(n, ops)
+        descriptors = ti.run(psi, images)
+        np.testing.assert_allclose(psi, want, rtol=0, atol=1e-12, err_msg=f"n={n} seed={seed}")
+        assert descriptors < len(ops)
