@@ -33,7 +33,7 @@ struct Tuning {
   int force_nt = -1;  // -1 auto, 0 never, 1 always
   int items = 0;      // 0 auto
   int max_gates_per_pass = 128;
-  int plan_lookahead = -1;   // tile-bit look-ahead of the pass builder: -1 auto (states of >= 24 qubits), 0 off, 1 on
+  int plan_lookahead = -1;   // tile-bit look-ahead of the pass builder: -1 auto (>= 24 qubits; two passes deep from 26), 0 off, 1 on, 2 two deep
   int tile_special = 1;      // real / Y-like / -1 / +-i special-case opcodes in fused passes
   int tile_merge_diag = 1;   // merge phase gates that share their predicate (OPC_DIAGR)
   int debug_skip_gates = 0;  // QSIM_DEBUG_SKIP_GATES=1: tile passes move data but apply nothing (WRONG results)

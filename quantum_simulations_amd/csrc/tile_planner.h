@@ -312,7 +312,8 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
 // the candidate that holds the most ops wins (first come on ties).  On the 28-qubit bench circuit
 // this needs 20-21 passes instead of 24 (tests/test_tile_planner_cpu.py); the search costs about
 // 0.3 ms per pass on the host, hidden behind the previous pass on the device for large states and
-// switched off for small ones (QSIM_PLAN_LOOKAHEAD = 0 / 1 forces).
+// switched off for small ones; from 26 qubits on each candidate is also scored by what the pass
+// AFTER it could hold (one pass fewer on the bench circuits).  QSIM_PLAN_LOOKAHEAD = 0 / 1 / 2 forces.
 // `sink(args, T, algorithmic_bytes)` receives every planned pass: the launcher on the device path,
 // a serialiser in qsim_plan_ops (the planner itself never touches the GPU).
 template <class Sink>
@@ -351,9 +352,14 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops, int* n_passes, Sin
     }
     return count;
   };
-  while (remaining) {
-    while (first < n_ops && done[first]) ++first;
-    // candidate 0: first come
+  // A pass is memory bound up to ~32 descriptors and pays ~0.03 ms for each one beyond that
+  // (tools/gate_cost_probe.py), so holding more than kSaturated ops buys nothing: a first-come pass
+  // that is already that full is kept (phase-heavy circuits: QFT).
+  constexpr int kSaturated = 64;
+  auto mask_of = [](const std::vector<int>& bits, size_t n) { u64 m = 0; for (size_t i = 0; i < n && i < bits.size(); ++i) m |= 1ull << bits[i]; return m; };
+  // candidate tiles for the next pass from the current `done` / `first`: [0] = first come, then the
+  // look-ahead ones grown from the first `seed` claimed bits
+  auto candidates = [&](std::vector<u64>* out, size_t max_seed, size_t seed_step) {
     std::vector<int> claimed;                   // high bits in the order they were claimed
     {
       u64 blocked = 0, mask = 0;
@@ -369,32 +375,50 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops, int* n_passes, Sin
         ++count;
       }
     }
-    auto mask_of = [](const std::vector<int>& bits, size_t n) { u64 m = 0; for (size_t i = 0; i < n && i < bits.size(); ++i) m |= 1ull << bits[i]; return m; };
-    u64 best_mask = mask_of(claimed, claimed.size());
-    int best_count = holds(best_mask, nullptr);
-    // A pass is memory bound up to ~32 descriptors and pays ~0.03 ms for each one beyond that
-    // (tools/gate_cost_probe.py), so holding more than kSaturated ops buys nothing: a first-come
-    // pass that is already that full is kept (phase-heavy circuits: QFT).
-    constexpr int kSaturated = 64;
-    best_count = std::min(best_count, kSaturated);
-    if (lookahead && k - low > cap && best_count < kSaturated) {
-      for (size_t seed = 0; seed <= 6 && seed <= claimed.size(); seed += 2) {
-        u64 mask = mask_of(claimed, seed);
-        int count = 0;
-        while (__builtin_popcountll(mask) < cap) {
-          int pick = -1, pick_count = -1;
-          for (int b = low; b < k; ++b) {
-            if ((mask >> b) & 1) continue;
-            const int c = holds(mask | (1ull << b), nullptr);
-            if (c > pick_count) { pick_count = c; pick = b; }
-          }
-          if (pick < 0) break;
-          mask |= 1ull << pick;
-          count = pick_count;
+    out->clear();
+    out->push_back(mask_of(claimed, claimed.size()));
+    if (!(lookahead && k - low > cap) || holds(out->front(), nullptr) >= kSaturated) return;
+    for (size_t seed = 0; seed <= max_seed && seed <= claimed.size(); seed += seed_step) {
+      u64 mask = mask_of(claimed, seed);
+      while (__builtin_popcountll(mask) < cap) {
+        int pick = -1, pick_count = -1;
+        for (int b = low; b < k; ++b) {
+          if ((mask >> b) & 1) continue;
+          const int c = holds(mask | (1ull << b), nullptr);
+          if (c > pick_count) { pick_count = c; pick = b; }
         }
-        count = std::min(count, kSaturated);
-        if (count > best_count) { best_count = count; best_mask = mask; }
+        if (pick < 0) break;
+        mask |= 1ull << pick;
       }
+      out->push_back(mask);
+    }
+  };
+  const bool depth2 = tune.plan_lookahead >= 0 ? tune.plan_lookahead >= 2 : k >= 26;
+  std::vector<u64> cands, cands2;
+  std::vector<size_t> trial;
+  while (remaining) {
+    while (first < n_ops && done[first]) ++first;
+    candidates(&cands, 6, 2);
+    u64 best_mask = cands[0];
+    int best_score = -1;
+    for (size_t ci = 0; ci < cands.size(); ++ci) {
+      trial.clear();
+      int score = std::min(holds(cands[ci], &trial), kSaturated);
+      if (depth2 && cands.size() > 1 && trial.size() < remaining) {
+        // what the pass AFTER this one could hold (a smaller candidate set)
+        const size_t first_saved = first;
+        for (size_t i : trial) done[i] = 1;
+        while (first < n_ops && done[first]) ++first;
+        candidates(&cands2, 4, 4);
+        int next_best = 0;
+        for (u64 m2 : cands2) next_best = std::max(next_best, std::min(holds(m2, nullptr), kSaturated));
+        for (size_t i : trial) done[i] = 0;
+        first = first_saved;
+        score += next_best;
+      } else if (depth2 && trial.size() >= remaining) {
+        score += 2 * kSaturated;                // finishes the list
+      }
+      if (score > best_score) { best_score = score; best_mask = cands[ci]; }
     }
     std::vector<int> high;                      // chosen high bits
     for (int b = low; b < k; ++b) if ((best_mask >> b) & 1) high.push_back(b);

@@ -47,14 +47,14 @@ def test_phase_runs_are_merged_and_ordered():
 
 
 def test_bench_workload_pass_count():
-    """The 28-qubit depth-40 bench circuit plans into 19 passes with the tile-bit look-ahead (24 with
-    the first-come rule alone); planning needs no device and no state."""
+    """The 28-qubit depth-40 bench circuit plans into 18 passes with the two-deep tile-bit look-ahead
+    (19 one deep, 24 with the first-come rule alone); planning needs no device."""
     from quantum_simulations_amd.circuit.fusion import batch_levels
     from quantum_simulations_amd.circuit.io import levelize, validate_circuit_dict
     from quantum_simulations_amd.circuits import random_1q_cx_circuit
     cd = validate_circuit_dict(random_1q_cx_circuit(28, depth=40))
     total = sum(len(ti.plan(28, p["local_ops"])) for p in batch_levels(levelize(cd), 28))
-    assert total == (24 if os.environ.get("QSIM_PLAN_LOOKAHEAD") == "0" else 19)
+    assert total == {"0": 24, "1": 19}.get(os.environ.get("QSIM_PLAN_LOOKAHEAD"), 18)
 
 
 def test_argument_budget_is_respected():
@@ -93,7 +93,7 @@ def test_lookahead_planner_on_small_states():
     if os.environ.get("QSIM_PLANNER_CHILD"):
         pytest.skip("already inside the child run")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for setting in ("1", "0"):
+    for setting in ("2", "1", "0"):
         env = dict(os.environ, QSIM_PLAN_LOOKAHEAD=setting, QSIM_PLANNER_CHILD="1", PYTHONPATH=root)
         out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", __file__],
                              cwd=root, env=env, capture_output=True, text=True, timeout=900)
