@@ -84,9 +84,9 @@ int qsim_apply_ops_unfused(qsim_chunk* c, int n_ops, const int32_t* nq, const in
 int qsim_last_pass_count(const qsim_chunk* c);
 /* The host planner of the fused passes WITHOUT a device (used by the CPU tests): plans the op list
  * for a 2^n_local_qubits chunk and writes one QSIM_PASS_IMAGE_BYTES pass image per planned pass to `out`
- * (layout = the kernel-argument block of k_tile: tile high bits, gate descriptors, matrix pool; the
- * tile size T in the `pad` field).  `out` may be NULL to count passes only.               */
-#define QSIM_PASS_IMAGE_BYTES 4000
+ * (layout = the kernel-argument block of k_tile, csrc/tile_kernel.h: record count, tile size T, tile high
+ * bits, then the record stream the gate engine interprets).  `out` may be NULL to count passes only. */
+#define QSIM_PASS_IMAGE_BYTES 4096
 int qsim_plan_ops(int n_local_qubits, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,
                   void* out, uint64_t out_capacity_bytes, int32_t* n_passes);
 

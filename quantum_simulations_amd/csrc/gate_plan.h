@@ -36,23 +36,28 @@ struct Tuning {
   int plan_lookahead = -1;   // tile-bit look-ahead of the pass builder: -1 auto (>= 24 qubits; two passes deep from 26), 0 off, 1 on, 2 two deep
   int tile_special = 1;      // real / Y-like / -1 / +-i special-case opcodes in fused passes
   int tile_merge_diag = 1;   // merge phase gates that share their predicate (OPC_DIAGR)
-  int debug_skip_gates = 0;  // QSIM_DEBUG_SKIP_GATES=1: tile passes move data but apply nothing (WRONG results)
+  int debug_skip_gates = 0;  // probe build only: QSIM_DEBUG_SKIP_GATES=1: tile passes move data but apply nothing (WRONG results)
   int debug_stats = 0;       // QSIM_DEBUG_STATS=1: print gates / groups per pass to stderr
   // States up to this size stay in the 256 MiB Infinity Cache between launches when accessed with
   // the default cache policy (tools/mall_probe.hip: 8.5-8.8 TB/s r+w for a 128-256 MiB region vs
   // 5.5 streaming); the NT policy bypasses it (6.0-6.2 at every size), so NT is for larger states.
   u64 mall_bytes = 256ull << 20;
   Tuning() {
-    if (const char* e = getenv("QSIM_MALL_BYTES")) mall_bytes = strtoull(e, nullptr, 10);
+    // Planning knobs: every setting yields a correct program (tests plan under several of them).
     if (const char* e = getenv("QSIM_DEBUG_STATS")) debug_stats = atoi(e);
-    if (const char* e = getenv("QSIM_SWZ_CUT")) swz_cut = atoi(e);
-    if (const char* e = getenv("QSIM_NT")) force_nt = atoi(e);
-    if (const char* e = getenv("QSIM_ITEMS")) items = atoi(e);
     if (const char* e = getenv("QSIM_PASS_GATES")) max_gates_per_pass = std::max(1, atoi(e));
     if (const char* e = getenv("QSIM_PLAN_LOOKAHEAD")) plan_lookahead = atoi(e);
     if (const char* e = getenv("QSIM_TILE_SPECIAL")) tile_special = atoi(e);
     if (const char* e = getenv("QSIM_TILE_MERGE_DIAG")) tile_merge_diag = atoi(e);
+#ifdef QSIM_PROBES
+    // Probe knobs (cache policy, launch shapes, gate-less passes that give WRONG results): only in the
+    // probe build `make probes` -> libqsim_hip_probes.so that tools/ loads; the product library has none.
+    if (const char* e = getenv("QSIM_MALL_BYTES")) mall_bytes = strtoull(e, nullptr, 10);
+    if (const char* e = getenv("QSIM_SWZ_CUT")) swz_cut = atoi(e);
+    if (const char* e = getenv("QSIM_NT")) force_nt = atoi(e);
+    if (const char* e = getenv("QSIM_ITEMS")) items = atoi(e);
     if (const char* e = getenv("QSIM_DEBUG_SKIP_GATES")) debug_skip_gates = atoi(e);
+#endif
   }
 };
 static const Tuning& tuning() {

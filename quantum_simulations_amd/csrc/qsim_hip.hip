@@ -260,7 +260,7 @@ int qsim_apply_ops_unfused(qsim_chunk* c, int n_ops, const int32_t* nq, const in
 int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats) {
   int rc = validate_ops(c, n_ops, nq, qubits, mats);
   if (rc) return rc;
-  if (n_ops < 2 || c->k < kTileMinChunk) {
+  if (n_ops < 2 || c->k < kTileMinChunk || c->k > kTileMaxQubits) {
     c->last_passes = n_ops;
     return qsim_apply_ops_unfused(c, n_ops, nq, qubits, mats);
   }
@@ -284,8 +284,8 @@ static_assert(sizeof(TileArgs) == QSIM_PASS_IMAGE_BYTES, "pass image = the kerne
 int qsim_plan_ops(int n_local_qubits, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,
                   void* out, uint64_t out_capacity_bytes, int32_t* n_passes) {
   if (!n_passes) return fail(QSIM_ERR_INVALID, "qsim_plan_ops: n_passes is null");
-  if (n_local_qubits < kTileMinChunk || n_local_qubits > 40)
-    return fail(QSIM_ERR_INVALID, "qsim_plan_ops: fused passes need %d..40 local qubits", kTileMinChunk);
+  if (n_local_qubits < kTileMinChunk || n_local_qubits > kTileMaxQubits)
+    return fail(QSIM_ERR_INVALID, "qsim_plan_ops: fused passes need %d..%d local qubits", kTileMinChunk, kTileMaxQubits);
   if (n_ops < 0 || (n_ops && (!nq || !qubits || !mats))) return fail(QSIM_ERR_INVALID, "bad op list");
   std::vector<FusedOp> ops;
   for (int i = 0; i < n_ops; ++i) {
@@ -304,7 +304,6 @@ int qsim_plan_ops(int n_local_qubits, int n_ops, const int32_t* nq, const int32_
   int rc = plan_fused(n_local_qubits, ops, &passes, [&](TileArgs& a, int T, double) {
     if (dst) {
       if (used + sizeof(TileArgs) > out_capacity_bytes) return fail(QSIM_ERR_INVALID, "qsim_plan_ops: output buffer too small");
-      a.pad = T;                                   // the image of a pass carries its tile size here
       std::memcpy(dst + used, &a, sizeof a);
     }
     used += sizeof(TileArgs);

@@ -121,25 +121,32 @@ static inline u64 op_qmask(const FusedOp& o) {
   return m;
 }
 
-// Matrix-pool entries an op needs under the opcode it will get.
-static int pool_entries(const FusedOp& o) {
+// The case an op gets once its register positions are known depends only on its kind and matrix:
+// family entry and matrix doubles of the record (tile_kernel.h, record stream).
+struct OpShape { int family; int nd; };
+static OpShape op_shape(const FusedOp& o) {
   const bool sp = tuning().tile_special;
   auto is = [&](int e, double re, double im) { return o.m[e].x == re && o.m[e].y == im; };
   switch (o.kind) {
-    case TG_SWAP1: return 0;
-    case TG_PHASE: return (sp && (is(0, -1, 0) || is(0, 0, 1) || is(0, 0, -1))) ? 0 : 1;
-    case TG_ANTI1: return (sp && is(1, 0, -1) && is(2, 0, 1)) ? 0 : 4;
-    case TG_DENSE2: return 16;
-    default:   // a real 2x2 (H, RY, G) packs its four entries into two: (u00, u01) and (u10, u11)
-      return (sp && o.kind == TG_DENSE1 && o.m[0].y == 0 && o.m[1].y == 0 && o.m[2].y == 0 && o.m[3].y == 0) ? 2 : 4;
+    case TG_SWAP1: return {OPC_SWAP1, 0};
+    case TG_PHASE:
+      if (sp && is(0, -1, 0)) return {OPC_PHASE_NEG, 0};
+      if (sp && is(0, 0, 1)) return {OPC_PHASE_I, 0};
+      if (sp && is(0, 0, -1)) return {OPC_PHASE_NI, 0};
+      return {OPC_PHASE, 2};
+    case TG_ANTI1: return (sp && is(1, 0, -1) && is(2, 0, 1)) ? OpShape{OPC_YLIKE1, 0} : OpShape{OPC_ANTI1, 4};
+    case TG_DENSE2: return {OPC_DENSE2, 32};
+    default:   // a real 2x2 (H, RY, G) needs four doubles instead of eight
+      return (sp && o.m[0].y == 0 && o.m[1].y == 0 && o.m[2].y == 0 && o.m[3].y == 0) ? OpShape{OPC_REAL1, 4}
+                                                                                        : OpShape{OPC_DENSE1, 8};
   }
 }
 
 // Split one pass's ops (list order) into register groups of <= kGroupBits target tile bits and
-// write the gate stream.  Ops that do not fit the argument budget stay un-emitted (they and
+// collect their descriptors.  Ops that do not fit the record budget stay un-emitted (they and
 // everything that depends on them wait for the next launch).
 static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_t>& members,
-                        const std::vector<int>& high, int T, TileArgs* a, std::vector<char>* emitted) {
+                        const std::vector<int>& high, int T, std::vector<TileGroup>* out, std::vector<char>* emitted) {
   const int low = kTileLow;
   auto tile_pos = [&](int b) -> int {
     if (b < low) return b;
@@ -148,40 +155,41 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
   };
   std::vector<char> done(members.size(), 0);
   size_t left = members.size();
-  a->ngates = 0;
-  int pool = 0;                       // next free matrix entry; 3 spare entries stay at the end
+  out->clear();
+  int used = 0;                       // bytes of the records written so far
+  const bool merge_on = tuning().tile_merge_diag != 0;
+  auto run_bytes = [](unsigned touched) { const int n = __builtin_popcount(touched); return desc_bytes(n == 1 ? 2 : (n == 2 ? 6 : 14)); };
   while (left) {
     std::vector<int> S;               // tile bits of this group
     std::vector<size_t> grp;          // indices into members
     u64 blocked = 0;
-    // Budget estimate in half units: a phase gate that may be merged with others (OPC_DIAGR) is
-    // counted as half a descriptor and half a pool entry; the exact budget is enforced when the
-    // group is written out (a group that overflows is cut there, the rest waits for the next pass).
-    int slots2 = 0, pool2 = 0;
-    const bool merge_on = tuning().tile_merge_diag != 0;
+    // Estimate: a phase gate that may be merged with others (OPC_DIAGR) is counted as a bare header; the
+    // exact budget is enforced when the group is written out (a group that overflows is cut there, the
+    // rest waits for the next pass).
+    int est = used + kGroupRecordBytes;
     for (size_t mi = 0; mi < members.size(); ++mi) {
       if (done[mi]) continue;
       const FusedOp& o = ops[members[mi]];
       const u64 qm = op_qmask(o);
       bool ok = !(blocked & qm);
       int need[2], nneed = 0;
-      const bool mergeable = merge_on && o.kind == TG_PHASE && pool_entries(o) == 1;
+      const OpShape shape = op_shape(o);
+      const bool mergeable = merge_on && shape.family == OPC_PHASE;
+      const int bytes = mergeable ? 16 : desc_bytes(shape.nd);
       if (ok) {
         for (int t = 0; t < o.ntargets; ++t) {
           const int p = tile_pos(o.target[t]);
           if (std::find(S.begin(), S.end(), p) == S.end()) need[nneed++] = p;
         }
         if ((int)S.size() + nneed > kGroupBits) ok = false;
-        if (2 * (a->ngates + 1) + slots2 + (mergeable ? 1 : 2) > 2 * kTileMaxGates || (int)grp.size() + 1 > 255) ok = false;
-        if (2 * pool + pool2 + (mergeable ? 1 : 2 * pool_entries(o)) > 2 * (kTileMaxMat - 3)) ok = false;
+        if (est + bytes > kTileRecordBudget) ok = false;
       }
       if (!ok) { blocked |= qm; continue; }
       for (int t = 0; t < nneed; ++t) S.push_back(need[t]);
       grp.push_back(mi);
-      slots2 += mergeable ? 1 : 2;
-      pool2 += mergeable ? 1 : 2 * pool_entries(o);
+      est += bytes;
     }
-    if (grp.empty()) break;           // argument budget exhausted: the rest waits for the next launch
+    if (grp.empty()) break;           // record budget exhausted: the rest waits for the next launch
     // pad the group with the highest unused tile bits (high bits keep LDS accesses contiguous)
     for (int b = T - 1; (int)S.size() < kGroupBits && b >= 0; --b)
       if (std::find(S.begin(), S.end(), b) == S.end()) S.push_back(b);
@@ -190,115 +198,120 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
       for (int j = 0; j < kGroupBits; ++j) if (S[j] == tile_bit) return j;
       return -1;
     };
-    TileGate hd;
-    std::memset(&hd, 0, sizeof hd);
-    hd.opcode = OPC_GROUP;
-    hd.blk_mask = (uint16_t)(S[0] | (S[1] << 4) | (S[2] << 8));
-    const int hd_at = a->ngates++;
-    int n_emitted = 0;
-    auto emit = [&](TileGate g, const double2* m, int nm) {
-      if (nm) {
-        g.mat = (uint16_t)pool;
-        for (int e = 0; e < nm; ++e) a->mat[pool + e] = m[e];
-        pool += nm;
-      }
-      put_gate(a, a->ngates++, g);
-      ++n_emitted;
+    TileGroup tg;
+    for (int j = 0; j < 3; ++j) tg.s[j] = S[j];
+    used += kGroupRecordBytes;
+    auto emit = [&](TileDesc d) {
+      used += desc_bytes(d);
+      tg.gates.push_back(d);
     };
     // Phase gates with ONE register bit and the same predicate (lane bits + outer bits) are merged
     // (the QFT's CR(k, a), CR(k, b), CR(k, c) for the group's register bits a, b, c): diagonal
     // gates commute with everything except a non-diagonal gate on one of their bits, so an open
     // accumulator is written out before such a gate on a register bit it has touched, or at the
-    // end of the group.  One descriptor instead of up to three: the gate loop is scalar-issue bound.
-    struct Acc { uint16_t blk; u64 outer; double2 phi[3]; unsigned touched; int count; TileGate single; };
+    // end of the group.  One record instead of up to three: the gate loop is instruction-issue bound.
+    struct Acc { uint16_t blk; u64 outer; double2 phi[3]; unsigned touched; };
     std::vector<Acc> open;
     bool cut = false;
+    auto cmul2 = [](double2 f, double2 m) { return make_double2(f.x * m.x - f.y * m.y, f.x * m.y + f.y * m.x); };
     auto flush = [&](size_t i) {
       const Acc acc = open[i];
       open.erase(open.begin() + (long)i);
-      if (acc.count == 1) { emit(acc.single, &acc.phi[__builtin_ctz(acc.touched)], 1); return; }
-      TileGate g;
-      std::memset(&g, 0, sizeof g);
-      g.blk_mask = acc.blk;
-      g.outer_mask = acc.outer;
+      TileDesc d;
+      std::memset(&d, 0, sizeof d);
+      d.blk_mask = acc.blk;
+      d.outer_mask = acc.outer;
       double2 m[3];
       int nm = 0;
       for (int r = 0; r < 3; ++r) if (acc.touched & (1u << r)) m[nm++] = acc.phi[r];
-      if (nm == 1) g.opcode = (uint8_t)(OPC_PHASE + acc.touched);
-      else g.opcode = (uint8_t)(OPC_DIAGR + (acc.touched == 3 ? 0 : acc.touched == 5 ? 1 : acc.touched == 6 ? 2 : 3));
-      emit(g, m, nm);
+      auto put = [&](int at, double2 v) { d.m[2 * at] = v.x; d.m[2 * at + 1] = v.y; };
+      if (nm == 1) {
+        d.opcode = (uint8_t)(OPC_PHASE + acc.touched);
+        put(0, m[0]); d.nd = 2;
+      } else if (nm == 2) {
+        d.opcode = (uint8_t)(OPC_DIAGR + (acc.touched == 3 ? 0 : acc.touched == 5 ? 1 : 2));
+        put(0, m[0]); put(1, m[1]); put(2, cmul2(m[0], m[1])); d.nd = 6;
+      } else {                          // a, b, c | ab, ac, bc, abc
+        d.opcode = (uint8_t)(OPC_DIAGR + 3);
+        const double2 ab = cmul2(m[0], m[1]);
+        put(0, m[0]); put(1, m[1]); put(2, m[2]);
+        put(3, ab); put(4, cmul2(m[0], m[2])); put(5, cmul2(m[1], m[2])); put(6, cmul2(ab, m[2]));
+        d.nd = 14;
+      }
+      emit(d);
     };
     for (size_t mi : grp) {
       const FusedOp& o = ops[members[mi]];
-      TileGate g;
-      std::memset(&g, 0, sizeof g);
+      TileDesc d;
+      std::memset(&d, 0, sizeof d);
       unsigned reg_mask = 0;
       int ctrl_reg = -1;
       auto require_one = [&](int qubit) {      // a control / phase bit
         const int p = tile_pos(qubit);
-        if (p < 0) { g.outer_mask |= 1ull << qubit; return; }
+        if (p < 0) { d.outer_mask |= 1ull << qubit; return; }
         const int r = reg_pos(p);
         if (r >= 0) { reg_mask |= 1u << r; ctrl_reg = r; }
-        else g.blk_mask |= (uint16_t)(1u << p);
+        else d.blk_mask |= (uint16_t)(1u << p);
       };
-      auto is = [&](int e, double re, double im) { return o.m[e].x == re && o.m[e].y == im; };
-      const bool sp = tuning().tile_special;
-      {   // exact budget: descriptors and pool entries written so far + what the open runs will need
-        int reserve_pool = 0;
-        for (const Acc& acc : open) reserve_pool += __builtin_popcount(acc.touched);
-        if (a->ngates + (int)open.size() + 1 > kTileMaxGates ||
-            pool + reserve_pool + std::max(1, pool_entries(o)) > kTileMaxMat - 3) { cut = true; break; }
+      const OpShape shape = op_shape(o);
+      {   // exact budget: records written so far + what the open runs may need + this op (a mergeable
+          // phase may grow a run to its largest form)
+        int reserve = 0;
+        for (const Acc& acc : open) reserve += run_bytes(acc.touched);
+        const bool mergeable = merge_on && shape.family == OPC_PHASE;
+        if (used + reserve + (mergeable ? desc_bytes(14) : desc_bytes(shape.nd)) > kTileRecordBudget) { cut = true; break; }
       }
       done[mi] = 1;
       (*emitted)[mi] = 1;
       --left;
+      auto put = [&](int at, double2 v) { d.m[2 * at] = v.x; d.m[2 * at + 1] = v.y; };
       if (o.kind == TG_PHASE) {
         for (int t = 0; t < o.nbits; ++t) require_one(o.bits[t]);
-        const int fam = !sp ? OPC_PHASE : (is(0, -1, 0) ? OPC_PHASE_NEG : (is(0, 0, 1) ? OPC_PHASE_I : (is(0, 0, -1) ? OPC_PHASE_NI : OPC_PHASE)));
-        g.opcode = (uint8_t)(fam + reg_mask);
-        if (tuning().tile_merge_diag && fam == OPC_PHASE && __builtin_popcount(reg_mask) == 1) {
+        d.opcode = (uint8_t)(shape.family + reg_mask);
+        if (merge_on && shape.family == OPC_PHASE && __builtin_popcount(reg_mask) == 1) {
           const int r = __builtin_ctz(reg_mask);
           size_t i = 0;
-          while (i < open.size() && !(open[i].blk == g.blk_mask && open[i].outer == g.outer_mask)) ++i;
+          while (i < open.size() && !(open[i].blk == d.blk_mask && open[i].outer == d.outer_mask)) ++i;
           if (i == open.size()) {
             Acc acc;
-            acc.blk = g.blk_mask; acc.outer = g.outer_mask; acc.touched = 0; acc.count = 0; acc.single = g;
+            acc.blk = d.blk_mask; acc.outer = d.outer_mask; acc.touched = 0;
             for (int e = 0; e < 3; ++e) acc.phi[e] = make_double2(1.0, 0.0);
             open.push_back(acc);
           }
           Acc& acc = open[i];
-          const double2 f = acc.phi[r], m = o.m[0];
-          acc.phi[r] = make_double2(f.x * m.x - f.y * m.y, f.x * m.y + f.y * m.x);
+          acc.phi[r] = cmul2(acc.phi[r], o.m[0]);
           acc.touched |= 1u << r;
-          ++acc.count;
           continue;
         }
+        if (shape.nd) { put(0, o.m[0]); d.nd = 2; }
       } else if (o.kind == TG_DENSE2) {
-        g.opcode = (uint8_t)(OPC_DENSE2 + 3 * reg_pos(tile_pos(o.target[0])) + reg_pos(tile_pos(o.target[1])));
+        d.opcode = (uint8_t)(OPC_DENSE2 + 3 * reg_pos(tile_pos(o.target[0])) + reg_pos(tile_pos(o.target[1])));
+        for (int e = 0; e < 16; ++e) put(e, o.m[e]);
+        d.nd = 32;
       } else {
         const int J = reg_pos(tile_pos(o.target[0]));
         if (o.control >= 0) require_one(o.control);
-        int fam = o.kind == TG_DENSE1 ? OPC_DENSE1 : (o.kind == TG_SWAP1 ? OPC_SWAP1 : OPC_ANTI1);
-        if (sp && o.kind == TG_DENSE1 && o.m[0].y == 0 && o.m[1].y == 0 && o.m[2].y == 0 && o.m[3].y == 0) fam = OPC_REAL1;
-        if (sp && o.kind == TG_ANTI1 && is(1, 0, -1) && is(2, 0, 1)) fam = OPC_YLIKE1;
-        g.opcode = (uint8_t)(fam + opc_1q_variant(J, ctrl_reg));
+        d.opcode = (uint8_t)(shape.family + opc_1q_variant(J, ctrl_reg));
+        if (shape.family == OPC_REAL1) {
+          d.m[0] = o.m[0].x; d.m[1] = o.m[1].x; d.m[2] = o.m[2].x; d.m[3] = o.m[3].x; d.nd = 4;
+        } else if (shape.family == OPC_ANTI1) {
+          put(0, o.m[1]); put(1, o.m[2]); d.nd = 4;
+        } else if (shape.family == OPC_DENSE1) {
+          for (int e = 0; e < 4; ++e) put(e, o.m[e]);
+          d.nd = 8;
+        }
       }
       if (o.kind != TG_PHASE) {               // a non-diagonal gate: its targets end the open phase runs on them
         unsigned tmask = 0;
         for (int t = 0; t < o.ntargets; ++t) tmask |= 1u << reg_pos(tile_pos(o.target[t]));
         for (size_t i = open.size(); i-- > 0;) if (open[i].touched & tmask) flush(i);
       }
-      if (g.opcode >= OPC_REAL1 && g.opcode < OPC_REAL1 + 9) {
-        const double2 packed[2] = {make_double2(o.m[0].x, o.m[1].x), make_double2(o.m[2].x, o.m[3].x)};
-        emit(g, packed, 2);
-      } else {
-        emit(g, o.m, std::min(pool_entries(o), o.nm));
-      }
+      emit(d);
     }
     while (!open.empty()) flush(0);
-    hd.count = (uint8_t)n_emitted;
-    put_gate(a, hd_at, hd);
-    if (cut) break;                   // argument budget exhausted inside the group
+    if (!tg.gates.empty()) out->push_back(tg);
+    else used -= kGroupRecordBytes;
+    if (cut) break;                   // record budget exhausted inside the group
   }
 }
 
@@ -429,6 +442,7 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops, int* n_passes, Sin
     for (int b = low; (int)high.size() < cap && b < k; ++b)
       if (std::find(high.begin(), high.end(), b) == high.end()) high.push_back(b);
     std::sort(high.begin(), high.end());
+#ifdef QSIM_PROBES
     if (tune.debug_skip_gates == 2) for (int j = 0; j < cap; ++j) high[j] = low + j;   // contiguous tiles (floor probe)
     if (tune.debug_skip_gates == 3) for (int j = 0; j < cap; ++j) high[j] = k - cap + j; // far-strided tiles
     if (tune.debug_skip_gates == 4) {   // tile bits from QSIM_DEBUG_TILE_BITS="b0,b1,..." (memory-pattern probe)
@@ -438,11 +452,14 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops, int* n_passes, Sin
         if ((int)bits.size() == cap) { high = bits; std::sort(high.begin(), high.end()); }
       }
     }
+#endif
     TileArgs a;
     std::memset(&a, 0, sizeof a);
+    a.T = T;
     for (size_t j = 0; j < high.size(); ++j) a.h[j] = (uint8_t)high[j];
     std::vector<char> emitted(members.size(), 0);
-    emit_groups(ops, members, high, T, &a, &emitted);
+    std::vector<TileGroup> groups;
+    emit_groups(ops, members, high, T, &groups, &emitted);
     size_t n_emitted = 0;
     double alg_bytes = 0;   // dense 32N, diagonal / controlled / SWAP 16N, CZ/CR 8N
     for (size_t mi = 0; mi < members.size(); ++mi)
@@ -453,13 +470,20 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops, int* n_passes, Sin
         done[members[mi]] = 1; --remaining; ++n_emitted;
       }
     if (!n_emitted) return fail(QSIM_ERR_INVALID, "internal: fused planner emitted nothing");
-    if (tune.debug_stats) {
-      int groups = 0;
-      for (int i = 0; i < a.ngates; ++i) groups += get_gate(&a, i).opcode == OPC_GROUP;
-      std::fprintf(stderr, "[qsim] pass %d: %zu gates, %d groups, %d entries\n", *n_passes, n_emitted, groups, a.ngates);
+#ifdef QSIM_PROBES
+    if (tune.debug_skip_gates) {                   // profiling aid: load -> LDS -> store only (WRONG results)
+      groups.resize(1);
+      groups[0].gates.clear();
     }
-    if (tune.debug_skip_gates) a.ngates = 0;       // profiling aid: load -> LDS -> store only
-    int rc = sink(a, T, alg_bytes);
+#endif
+    int rc = serialize_pass(groups, &a);
+    if (rc) return rc;
+    if (tune.debug_stats) {
+      size_t descs = 0;
+      for (const TileGroup& g : groups) descs += g.gates.size();
+      std::fprintf(stderr, "[qsim] pass %d: %zu gates, %zu groups, %zu descriptors\n", *n_passes, n_emitted, groups.size(), descs);
+    }
+    rc = sink(a, T, alg_bytes);
     if (rc) return rc;
     ++*n_passes;
   }
@@ -479,9 +503,7 @@ static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_pass
     (void)hipEventSynchronize(e1);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    int groups = 0, gates = 0;
-    for (int i = 0; i < a.ngates; ++i) (get_gate(&a, i).opcode == OPC_GROUP ? groups : gates)++;
-    std::fprintf(stderr, "[qsim] timed pass: %.3f ms, %d descriptors, %d groups, high bits", ms, gates, groups);
+    std::fprintf(stderr, "[qsim] timed pass: %.3f ms, %d records, high bits", ms, a.nrec);
     for (int j = 0; j < T - kTileLow; ++j) std::fprintf(stderr, " %d", a.h[j]);
     std::fprintf(stderr, "\n");
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

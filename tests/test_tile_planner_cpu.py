@@ -42,8 +42,8 @@ def test_phase_runs_are_merged_and_ordered():
     descriptors = ti.run(psi, images)
     np.testing.assert_allclose(psi, orc.simulate(cd), rtol=0, atol=1e-12)
     assert descriptors < len(ops)                                   # merging happened
-    assert any(int(g["opcode"]) >= ti.OPC["DIAGR"] and int(g["opcode"]) != ti.OPC["GROUP"]
-               for img in images for g in img["g"][:int(img["ngates"])])
+    assert any(rec[0] == "gate" and ti.OPC["DIAGR"] <= rec[1] < ti.OPC["DIAGR"] + 4
+               for img in images for rec in ti.records(img))
 
 
 def test_bench_workload_pass_count():
@@ -58,8 +58,8 @@ def test_bench_workload_pass_count():
 
 
 def test_argument_budget_is_respected():
-    """Many dense 2q gates (16 pool entries each): passes are cut by the matrix-pool budget and
-    every image stays within the descriptor / pool capacity."""
+    """Many dense 2q gates (272-byte records): passes are cut by the record budget of the 4 KiB argument
+    block and every image stays inside it (ti.records asserts the bounds of every 64-byte fetch)."""
     n = 10
     rng = np.random.default_rng(8)
     ops = []
@@ -68,14 +68,14 @@ def test_argument_budget_is_respected():
         z = rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4))
         ops.append(([qa, qb], np.linalg.qr(z)[0]))
     images = ti.plan(n, ops)
-    assert len(images) >= 60 * 16 // (ti.MAX_MAT - 3)
+    assert len(images) >= 60 * 272 // (ti.IMAGE_BYTES - ti.STREAM_OFF)
     psi = _rand_state(n, 5)
     want = psi.copy()
     orc.apply_ops(want, ops)
     ti.run(psi, images)
     np.testing.assert_allclose(psi, want, rtol=0, atol=1e-12)
     for img in images:
-        assert 0 < int(img["ngates"]) < ti.MAX_GATES
+        assert 2 < int(img["nrec"]) and sum(1 for _ in ti.records(img)) == int(img["nrec"]) - 1
 
 
 def test_plan_ops_rejects_bad_input():

@@ -1,9 +1,10 @@
 """numpy interpreter of the fused-pass images that `qsim_plan_ops` emits (test infrastructure).
 
-The device kernel `k_tile` executes a pass image (csrc/tile_kernel.h: group headers + one opcode
-byte per gate, predicate masks, matrix pool); this module executes the SAME image on a numpy
-state, following the opcode table, so the host planner -- pass building, register groups, opcode
-and mask encoding, merged phase runs, ordering -- is checked on the CPU without a GPU.
+The device kernel `k_tile` interprets the record stream of a pass image (csrc/tile_kernel.h: group
+records, one record per gate = branch-table entry, predicate masks, matrix doubles); this module walks
+the SAME stream on a numpy state, following the entry table, so the host planner -- pass building,
+register groups, entry and mask encoding, record layout, merged phase runs, ordering -- is checked on
+the CPU without a GPU.
 """
 from __future__ import annotations
 
@@ -14,15 +15,73 @@ import numpy as np
 from quantum_simulations_amd import _lib
 from quantum_simulations_amd.kernel.device import pack_ops
 
-IMAGE_BYTES = 4000
-MAX_GATES, MAX_MAT = 144, 104      # descriptor slots (143 usable: the device reads one entry ahead), pool entries
+IMAGE_BYTES = 4096
+STREAM_OFF = 32                    # byte offset of the first record (csrc/tile_kernel.h)
 OPC = dict(DENSE1=1, SWAP1=10, ANTI1=19, PHASE=28, DENSE2=36, REAL1=45, YLIKE1=54, PHASE_NEG=63,
-           PHASE_I=71, PHASE_NI=79, DIAGR=87, GROUP=0xFE)
-_GATE = np.dtype([("opcode", "u1"), ("count", "u1"), ("blk_mask", "<u2"), ("mat", "<u2"), ("pad", "<u2"),
-                  ("outer_mask", "<u8")])
-_IMAGE = np.dtype([("amp", "<u8"), ("ngates", "<i4"), ("T", "<i4"), ("h", "u1", (16,)),
-                   ("g", _GATE, (MAX_GATES,)), ("mat", "<c16", (MAX_MAT,))])
+           PHASE_I=71, PHASE_NI=79, DIAGR=87, PRED_OUTER=91, PRED_LANE=92, GROUP=93, GROUP_FIRST=94, END=95)
+_FAMILIES = ("DENSE1", "SWAP1", "ANTI1", "PHASE", "DENSE2", "REAL1", "YLIKE1", "PHASE_NEG", "PHASE_I", "PHASE_NI", "DIAGR")
+_IMAGE = np.dtype([("amp", "<u8"), ("nrec", "<i4"), ("T", "<i4"), ("h", "u1", (16,)),
+                   ("stream", "u1", (IMAGE_BYTES - STREAM_OFF,))])
 assert _IMAGE.itemsize == IMAGE_BYTES
+
+
+def lds_slot(t: int) -> int:
+    return t ^ ((t >> 4) & 15)
+
+
+def records(img):
+    """Walk the record stream of a pass image the way the gate engine does: yields
+    ("group", [s0, s1, s2]) and ("gate", opcode, blk_mask, outer_mask, doubles_at(k), size) tuples."""
+    raw = bytes(img.tobytes())
+    assert len(raw) == IMAGE_BYTES
+    off = STREAM_OFF
+    seen_group = False
+    count = 0
+    while True:
+        assert off % 16 == 0 and off + 64 <= IMAGE_BYTES, f"record at {off}: the 64-byte fetch leaves the block"
+        d = np.frombuffer(raw, dtype="<u4", count=16, offset=off)
+        assert d[0] % 4 == 0
+        entry, nxt = int(d[0]) // 4, int(d[1])
+        count += 1
+        if entry == OPC["END"]:
+            assert nxt == off and seen_group
+            assert count == int(img["nrec"]), (count, int(img["nrec"]))
+            return
+        assert off < nxt <= IMAGE_BYTES - 64 and nxt % 16 == 0, (off, nxt)
+        if entry in (OPC["GROUP"], OPC["GROUP_FIRST"]):
+            assert (entry == OPC["GROUP_FIRST"]) == (not seen_group)
+            seen_group = True
+            assert nxt == off + 48
+            s = []
+            for i in range(3):
+                m = int(d[2 + i])
+                sh = (m & -m).bit_length() - 1
+                assert m == (0xFFFFFFFF << sh) & 0xFFFFFFFF
+                s.append(sh)
+            for r in range(1, 8):
+                t = sum(1 << s[i] for i in range(3) if (r >> i) & 1)
+                assert int(d[4 + r]) == lds_slot(t) << 4, "LDS XOR constant"
+            yield ("group", s)
+        else:
+            assert seen_group, "gate before the first group"
+            blk, case = int(d[3]) & 0xFFFF, (int(d[3]) >> 16) // 4
+            outer = int(d[2]) << 3
+            if entry == OPC["PRED_LANE"]:
+                assert blk
+            elif entry == OPC["PRED_OUTER"]:
+                assert outer and not blk
+            else:
+                assert entry == case and not blk and not outer, (entry, case, blk, outer)
+            size = nxt - off
+
+            def doubles(k, n, off=off, size=size, raw=raw):
+                """n doubles starting at the k-th in-record double; entries beyond the 6th sit at the end"""
+                return np.frombuffer(raw, dtype="<f8", count=n, offset=off + 16 + 8 * k)
+
+            def tail(nbytes, off=off, size=size, raw=raw):
+                return np.frombuffer(raw, dtype="<f8", count=nbytes // 8, offset=off + size - nbytes)
+            yield ("gate", case, blk, outer, doubles, tail, size)
+        off = nxt
 
 
 def plan(n_qubits: int, ops) -> np.ndarray:
@@ -56,6 +115,10 @@ def _apply_2q(psi, idx, qa_bit, qb_bit, U, cond_mask):
         psi[s] = row
 
 
+def _c(v):
+    return complex(v[0], v[1])
+
+
 def run_pass(psi: np.ndarray, img) -> int:
     """Execute one pass image on `psi` in place; returns the number of gate descriptors run."""
     T = int(img["T"])
@@ -70,55 +133,84 @@ def run_pass(psi: np.ndarray, img) -> int:
     def abs_mask(tile_mask: int) -> int:
         return sum(1 << abs_bit(b) for b in range(T) if (tile_mask >> b) & 1)
 
-    g, mat, ngates = img["g"], img["mat"], int(img["ngates"])
-    i = 0
     run = 0
-    while i < ngates:
-        hd = g[i]
-        assert hd["opcode"] == OPC["GROUP"], (i, hd["opcode"])
-        s = [(int(hd["blk_mask"]) >> (4 * j)) & 15 for j in range(3)]
-        assert s[0] < s[1] < s[2] < T, s
-        A = [abs_bit(b) for b in s]                                     # absolute index bit of register bit j
-        for d in g[i + 1:i + 1 + int(hd["count"])]:
-            op, m = int(d["opcode"]), int(d["mat"])
-            assert not (int(d["blk_mask"]) & sum(1 << b for b in s)), "lane predicate on a register bit"
-            cond = abs_mask(int(d["blk_mask"])) | int(d["outer_mask"])
-            fam = max(v for v in OPC.values() if v <= op and v != OPC["GROUP"])
-            var = op - fam
-            if fam in (OPC["DENSE1"], OPC["SWAP1"], OPC["ANTI1"], OPC["REAL1"], OPC["YLIKE1"]):
-                if var < 3:
-                    J, ctrl = var, None
-                else:
-                    J, kk = (var - 3) // 2, (var - 3) % 2
-                    ctrl = [r for r in range(3) if r != J][kk]
-                if fam == OPC["SWAP1"]:
-                    U = np.array([[0, 1], [1, 0]], dtype=complex)
-                elif fam == OPC["YLIKE1"]:
-                    U = np.array([[0, -1j], [1j, 0]])
-                elif fam == OPC["ANTI1"]:
-                    U = np.array([[0, mat[m + 1]], [mat[m + 2], 0]])
-                elif fam == OPC["REAL1"]:       # packed: entry 0 = (r00, r01), entry 1 = (r10, r11)
-                    U = np.array([[mat[m].real, mat[m].imag], [mat[m + 1].real, mat[m + 1].imag]], dtype=complex)
-                else:
-                    U = mat[m:m + 4].reshape(2, 2)
-                _apply_1q(psi, idx, A[J], U, cond | (0 if ctrl is None else 1 << A[ctrl]))
-            elif fam in (OPC["PHASE"], OPC["PHASE_NEG"], OPC["PHASE_I"], OPC["PHASE_NI"]):
-                f = {OPC["PHASE"]: mat[m], OPC["PHASE_NEG"]: -1, OPC["PHASE_I"]: 1j, OPC["PHASE_NI"]: -1j}[fam]
-                need = cond | sum(1 << A[r] for r in range(3) if (var >> r) & 1)
-                psi[(idx & need) == need] *= f
-            elif fam == OPC["DIAGR"]:
-                regs = {0: (0, 1), 1: (0, 2), 2: (1, 2), 3: (0, 1, 2)}[var]
-                on = (idx & cond) == cond
-                for e, r in enumerate(regs):
-                    psi[on & ((idx >> A[r]) & 1 == 1)] *= mat[m + e]
-            elif fam == OPC["DENSE2"]:
-                JA, JB = var // 3, var % 3
-                assert JA != JB
-                _apply_2q(psi, idx, A[JA], A[JB], mat[m:m + 16].reshape(4, 4), cond)
+    A = None
+    s = None
+    for rec in records(img):
+        if rec[0] == "group":
+            s = rec[1]
+            assert s[0] < s[1] < s[2] < T, s
+            A = [abs_bit(b) for b in s]                                 # absolute index bit of register bit j
+            continue
+        _, op, blk, outer, dbl, tail, size = rec
+        assert not (blk & sum(1 << b for b in s)), "lane predicate on a register bit"
+        assert not (outer & sum(1 << abs_bit(b) for b in range(T))), "outer predicate on a tile bit"
+        cond = abs_mask(blk) | outer
+        fam = max(OPC[f] for f in _FAMILIES if OPC[f] <= op)
+        var = op - fam
+        if fam in (OPC["DENSE1"], OPC["SWAP1"], OPC["ANTI1"], OPC["REAL1"], OPC["YLIKE1"]):
+            assert 0 <= var < 9
+            if var < 3:
+                J, ctrl = var, None
             else:
-                raise AssertionError(f"unknown opcode {op}")
-            run += 1
-        i += 1 + int(hd["count"])
+                J, kk = (var - 3) // 2, (var - 3) % 2
+                ctrl = [r for r in range(3) if r != J][kk]
+            if fam == OPC["SWAP1"]:
+                U = np.array([[0, 1], [1, 0]], dtype=complex)
+                assert size == 16
+            elif fam == OPC["YLIKE1"]:
+                U = np.array([[0, -1j], [1j, 0]])
+                assert size == 16
+            elif fam == OPC["ANTI1"]:
+                m = dbl(0, 4)
+                U = np.array([[0, _c(m[0:2])], [_c(m[2:4]), 0]])
+                assert size == 48
+            elif fam == OPC["REAL1"]:
+                m = dbl(0, 4)
+                U = np.array([[m[0], m[1]], [m[2], m[3]]], dtype=complex)
+                assert size == 48
+            else:
+                m = dbl(0, 6)
+                u11 = tail(16)
+                U = np.array([[_c(m[0:2]), _c(m[2:4])], [_c(m[4:6]), _c(u11)]])
+                assert size == 80
+            _apply_1q(psi, idx, A[J], U, cond | (0 if ctrl is None else 1 << A[ctrl]))
+        elif fam in (OPC["PHASE"], OPC["PHASE_NEG"], OPC["PHASE_I"], OPC["PHASE_NI"]):
+            assert 0 <= var < 8
+            if fam == OPC["PHASE"]:
+                f = _c(dbl(0, 2))
+                assert size == 32
+            else:
+                f = {OPC["PHASE_NEG"]: -1, OPC["PHASE_I"]: 1j, OPC["PHASE_NI"]: -1j}[fam]
+                assert size == 16
+            need = cond | sum(1 << A[r] for r in range(3) if (var >> r) & 1)
+            psi[(idx & need) == need] *= f
+        elif fam == OPC["DIAGR"]:
+            assert 0 <= var < 4
+            regs = {0: (0, 1), 1: (0, 2), 2: (1, 2), 3: (0, 1, 2)}[var]
+            on = (idx & cond) == cond
+            m = dbl(0, 6)
+            u = [_c(m[0:2]), _c(m[2:4]), _c(m[4:6])]
+            if var < 3:
+                assert size == 64 and abs(u[2] - u[0] * u[1]) < 1e-15       # the product the engine uses
+                phases = u[:2]
+            else:
+                assert size == 128
+                t = tail(64)
+                prods = [_c(t[0:2]), _c(t[2:4]), _c(t[4:6]), _c(t[6:8])]
+                want = [u[0] * u[1], u[0] * u[2], u[1] * u[2], u[0] * u[1] * u[2]]
+                assert max(abs(a - b) for a, b in zip(prods, want)) < 1e-15
+                phases = u
+            for e, r in enumerate(regs):
+                psi[on & ((idx >> A[r]) & 1 == 1)] *= phases[e]
+        elif fam == OPC["DENSE2"]:
+            JA, JB = var // 3, var % 3
+            assert JA != JB and JA < 3 and size == 272
+            m = tail(256)
+            _apply_2q(psi, idx, A[JA], A[JB], (m[0::2] + 1j * m[1::2]).reshape(4, 4), cond)
+        else:
+            raise AssertionError(f"unknown opcode {op}")
+        run += 1
     return run
 
 
