@@ -1,20 +1,20 @@
 #!/usr/bin/env python3
-"""Headline benchmark: gate-applications/sec (and achieved HBM GB/s) of the gate-application
-hot path on MI355X.
+"""Headline benchmark: gate-applications/sec and achieved HBM GB/s of the gate-application hot
+path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run ... bench.py --gpus N --dry-run     # comm schedule only (gloo, no shards)
 
-Workload (BASELINE.json configs[1]): the seeded random 1q+CX circuit, depth 40, on
-n = 28 + log2(N) qubits -- 2^28 complex128 amplitudes (4 GiB) per GPU, weak scaling.  One
-"step" = one execution of the whole circuit on the HBM-resident state (the state is already
-in HBM when the timed region starts; nothing crosses PCIe inside it).
+Workload: the seeded random 1q+CX circuit, depth 40 (BASELINE configs[1]).  N = 1: 28 qubits (4 GiB,
+the configuration the metric is quoted on).  N > 1: 30 LOCAL qubits per GPU (16 GiB shards, weak
+scaling: n = 30 + log2 N, so --gpus 8 is the 33-qubit run the north star names).  One "step" = one
+execution of the whole circuit on the HBM-resident state; nothing crosses PCIe in the timed region.
 
-`value` counts shard-level gate-applications per second summed over ranks (one gate of the
-circuit applied to one rank's 2^28-amplitude shard = 1 unit; at N = 1 this is exactly
-gate-applications/sec of the circuit).  `global_gate_apps_per_s` is the whole-state figure.
-Rank 0 prints ONE JSON line.
+`value` = gate-applications per second of the WHOLE 2^n state at every N (one gate of the
+circuit applied to the full state = 1).  Rank 0 prints ONE JSON line and exits non-zero when the run
+is invalid (parity or norm check failed, probe knobs in the environment).
 """
 from __future__ import annotations
 
@@ -31,23 +31,40 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
-LOCAL_QUBITS = 28
+PARITY_TOL = 1e-10
+NORM_TOL = 1e-9
+ALLOWED_ENV = {"QSIM_DIST_BACKEND"}      # rehearsal switch of the distributed engine (gloo on one GPU)
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--local-qubits", type=int, default=LOCAL_QUBITS)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--local-qubits", type=int, default=0, help="default: 28 at N = 1, 30 at N > 1")
     ap.add_argument("--depth", type=int, default=40)
     ap.add_argument("--mode", choices=["fused", "per-gate"], default="fused",
                     help="fused: planner passes (batch_levels + tile fusion); per-gate: one launch per gate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--no-sweep", action="store_true", help="skip the per-target H sweep (config 3)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the per-target sweeps (config 3)")
     ap.add_argument("--sweep-qubits", type=int, default=30)
+    ap.add_argument("--sustain-seconds", type=float, default=3.0,
+                    help="second, longer timed region after the K-step one (0 = off)")
+    ap.add_argument("--no-configs", action="store_true", help="N > 1: skip the config-4 / config-5 sub-runs")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="N > 1: print and cross-check the communication schedule only (gloo, no shard memory)")
     return ap.parse_args()
+
+
+def refuse_probe_environment():
+    """A QSIM_* variable changes planning (or, in the probe build, results): a number timed under one
+    is not the product's number."""
+    bad = sorted(k for k in os.environ if k.startswith("QSIM_") and k not in ALLOWED_ENV)
+    if bad:
+        print(json.dumps({"error": "refusing to run with tuning / probe knobs in the environment", "knobs": bad}),
+              flush=True)
+        sys.exit(2)
 
 
 def host_core_share() -> int:
@@ -66,7 +83,8 @@ def host_core_share() -> int:
     return cores
 
 
-def cpu_baseline(circuit: dict, budget_s: float) -> dict:
+# ---------------------------------------------------------------------------------- CPU columns
+def cpu_baseline(circuit: dict, budget_s: float):
     """Time the C oracle (oracle/qsim_oracle.c, OpenMP over all host cores) on the first gates
     of the same circuit, on the same 2^n state size, for about `budget_s` seconds."""
     from oracle import c_oracle, dense_oracle
@@ -93,24 +111,49 @@ def cpu_baseline(circuit: dict, budget_s: float) -> dict:
                       f"oracle/qsim_oracle.c with OpenMP, {dt:.1f} s)"}, psi, done
 
 
-def cpu_v1_sql_baseline() -> dict:
-    """BASELINE config 1: the v1 SQL engine's algorithm (oracle/v1_sql_oracle.py, stdlib sqlite3,
-    one thread) on the 20-qubit GHZ circuit."""
-    from oracle import v1_sql_oracle
+def cpu_config1_columns() -> dict:
+    """BASELINE config 1 (20-qubit GHZ: H + CNOT ladder, complex128, single process) on this node's
+    host cores, three ways: the v1 SQL engine's algorithm on stdlib sqlite3 (1 core),
+    the numpy restatement of cpu_scalar.apply_1q / apply_2q (1 thread), the C loop with OpenMP."""
+    from oracle import c_oracle, dense_oracle, v1_sql_oracle
     n = 20
     gates = [{"qubits": [0], "gate": "H"}] + [{"qubits": [q - 1, q], "gate": "CNOT"} for q in range(1, n)]
+    cd = {"number_of_qubits": n, "gates": gates}
+    want0 = 0.7071067811865475
+
+    def exact(psi) -> bool:
+        return bool(abs(psi[0] - want0) < 1e-15 and abs(psi[-1] - want0) < 1e-15 and np.count_nonzero(psi) == 2)
+
+    out = {}
     t0 = time.perf_counter()
-    psi = v1_sql_oracle.run_circuit({"number_of_qubits": n, "gates": gates})
+    psi = v1_sql_oracle.run_circuit(cd)
     dt = time.perf_counter() - t0
-    ok = bool(psi[0] == psi[-1] == 0.7071067811865475 and np.count_nonzero(psi) == 2)
-    return {"value": n / dt, "unit": "gate-applications/s", "cores": 1, "kind": "port",
-            "sample": f"20-qubit GHZ (20 gates), v1 SQL algorithm restated on stdlib sqlite3, {dt:.1f} s",
-            "amplitudes_exact": ok}
+    out["v1_sql_sqlite3"] = {"value": n / dt, "unit": "gate-applications/s", "cores": 1, "kind": "port",
+                             "sample": f"20-qubit GHZ (20 gates), v1 SQL algorithm restated on stdlib sqlite3, {dt:.2f} s",
+                             "amplitudes_exact": exact(psi)}
+    t0 = time.perf_counter()
+    psi = dense_oracle.simulate(cd)
+    dt = time.perf_counter() - t0
+    out["numpy_dense_1_thread"] = {"value": n / dt, "unit": "gate-applications/s", "cores": 1, "kind": "port",
+                                   "sample": f"20-qubit GHZ, oracle/dense_oracle.py (restatement of cpu_scalar.apply_1q/2q, "
+                                             f"pinned by golden G3), {dt:.2f} s",
+                                   "amplitudes_exact": exact(psi)}
+    c_oracle.set_threads(host_core_share())
+    c_oracle.simulate(cd)                                    # warm the thread pool
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        psi = c_oracle.simulate(cd)
+    dt = (time.perf_counter() - t0) / reps
+    out["c_openmp"] = {"value": n / dt, "unit": "gate-applications/s", "cores": c_oracle.num_threads(), "kind": "port",
+                       "sample": f"20-qubit GHZ, oracle/qsim_oracle.c with OpenMP, {dt * 1e3:.1f} ms per run",
+                       "amplitudes_exact": exact(psi)}
+    return out
 
 
 def pmc_traffic_per_launch(kernel_prefix: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_summary.json, written by tools/pmc_summary.py); None if absent."""
+    (profiles/*_pmc_summary.json, written by tools/pmc_summary.py; the newest round wins); None if absent."""
     best = None
     for path in sorted((ROOT / "profiles").glob("*_pmc_summary.json")):
         try:
@@ -123,35 +166,130 @@ def pmc_traffic_per_launch(kernel_prefix: str):
     return best
 
 
-def main():
-    args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    if world & (world - 1):
-        raise SystemExit("number of GPUs must be a power of two (shards are indexed by high qubits)")
-
+# ---------------------------------------------------------------------------------- N = 1
+def run_single(args, k: int) -> tuple[dict, list[str]]:
     from quantum_simulations_amd.circuits import random_1q_cx_circuit
     from quantum_simulations_amd.runner.engine import make_engine
 
-    k = args.local_qubits
-    n = k + (world.bit_length() - 1)
+    invalid: list[str] = []
+    n = k
     circuit = random_1q_cx_circuit(n, depth=args.depth)
     n_gates = len(circuit["gates"])
-
-    engine = make_engine(n, world, rank, local_rank, mode=args.mode)
+    engine = make_engine(n, 1, 0, int(os.environ.get("LOCAL_RANK", "0")), mode=args.mode)
     engine.init_zero_state()
     plan = engine.plan(circuit, repeats=args.warmup + args.steps)
-
     for _ in range(args.warmup):
         engine.execute(plan)
     engine.barrier()
-    if hasattr(engine, "reset_comm_stats"):
-        engine.reset_comm_stats()
+    engine.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        engine.execute(plan)
+    engine.barrier()
+    dt = time.perf_counter() - t0
+    prof = engine.profile_end()
+    norm2 = engine.norm2()
+    passes = engine.passes_per_step(plan)
+    if abs(norm2 - 1.0) > NORM_TOL:
+        invalid.append(f"|norm2 - 1| = {abs(norm2 - 1.0):.3e} > {NORM_TOL}")
+
+    # a second, longer timed region (no per-launch events): the same step repeated for ~sustain_seconds
+    sustained = None
+    if args.sustain_seconds > 0:
+        reps = max(args.steps, int(args.sustain_seconds / max(dt / args.steps, 1e-6)))
+        engine.barrier()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            engine.execute(plan)
+        engine.barrier()
+        dt_s = time.perf_counter() - t1
+        sustained = {"steps": reps, "seconds": round(dt_s, 3), "gate_apps_per_s": round(n_gates * reps / dt_s, 1),
+                     "ms_per_step": round(dt_s / reps * 1e3, 3)}
+
+    copy = engine.copy_ceiling()                     # same-run device-to-device copy of a same-size buffer
+    dom = max(prof, key=lambda e: e["total_ms"]) if prof else None
+    roofline = None
+    if dom:
+        secs = dom["total_ms"] * 1e-3
+        moved = dom["hbm_bytes"] / secs / 1e9
+        roofline = {"bound": "hbm", "achieved": round(moved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(moved / HBM_PEAK_GBS, 4),
+                    "traffic": pmc_traffic_per_launch(dom["kernel"].split(" ")[0]),
+                    "kernel": dom["kernel"], "launches": dom["launches"],
+                    "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4),
+                    "bytes_per_launch": dom["hbm_bytes"] / dom["launches"],
+                    "copy_ceiling_GBps": copy["GBps"], "frac_of_copy_ceiling": round(moved / copy["GBps"], 4),
+                    "gates_per_launch": round(n_gates * args.steps / dom["launches"], 2),
+                    "algorithmic_GBps": round(dom["algorithmic_bytes"] / secs / 1e9, 1),
+                    "note": "achieved = bytes the launch itself reads+writes (32 B per amplitude of the shard) / "
+                            "HIP-event time of the launches in the timed region; algorithmic_GBps sums SURVEY 8d's "
+                            "per-gate bytes over the gates a fused launch applies (it may exceed the physical peak "
+                            "and is not a roofline fraction)"}
+    out = {
+        "metric": "gate-applications/sec (random 1q+CX circuit, complex128 statevector)",
+        "value": round(n_gates * args.steps / dt, 2), "unit": "gate-applications/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{n}-qubit random 1q+CX circuit depth {args.depth} (seed 20260228), "
+                               f"{n_gates} gates, complex128, {k} local qubits per GPU",
+                   "n_qubits": n, "local_qubits": k, "gates_per_step": n_gates, "mode": args.mode,
+                   "hbm_passes_per_step": passes},
+        "timed_seconds": round(dt, 4),
+        "sustained": sustained,
+        "norm2_after": norm2,
+        "roofline": roofline,
+        "copy_ceiling": copy,
+        "kernel_breakdown": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof],
+    }
+    if not args.no_sweep:
+        # BASELINE config 3 / north-star target: one gate per launch on a 30-qubit random state (no fusion
+        # across the timed gates), every target index, fractions of the 8 TB/s peak of SURVEY 8d's
+        # algorithmic bytes (H 32 N, T and CNOT 16 N)
+        sw = engine.sweep_gates(args.sweep_qubits)
+        out["sweep30"] = sw
+        h = sw["rows"]["H(q)"]
+        out["roofline_per_gate_kernel"] = {
+            "bound": "hbm", "kernel": "k_gate<2> / k_gate_shuffle<1,1>: dense 1q, one launch per gate",
+            "achieved": round(h["median_frac"] * HBM_PEAK_GBS, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": h["median_frac"], "min_frac_over_targets": h["min_frac"],
+            "workload": f"H on every target of a {sw['n_qubits']}-qubit state (32 B x 2^n per launch)"}
+    if not args.no_cpu_baseline:
+        base, psi_cpu, done = cpu_baseline(circuit, args.cpu_seconds)
+        out["cpu_baseline"] = base
+        out["vs_cpu_baseline"] = round(out["value"] / base["value"], 1)
+        # parity of the same prefix on the GPU (outside every timed region)
+        par = engine.prefix_parity(circuit, done, psi_cpu)
+        out["parity_max_abs_diff_vs_cpu_prefix"] = par
+        if not par <= PARITY_TOL:
+            invalid.append(f"parity vs CPU prefix {par:.3e} > {PARITY_TOL}")
+        del psi_cpu
+        out["cpu_baseline_config1"] = cpu_config1_columns()
+        for name, col in out["cpu_baseline_config1"].items():
+            if not col["amplitudes_exact"]:
+                invalid.append(f"config-1 CPU column {name}: wrong GHZ amplitudes")
+    engine.close()
+    return out, invalid
+
+
+# ---------------------------------------------------------------------------------- N > 1
+def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dict | None, list[str]]:
+    from quantum_simulations_amd import circuits as gen
+    from quantum_simulations_amd.runner.engine import make_engine
+
+    invalid: list[str] = []
+    p = world.bit_length() - 1
+    n = k + p
+    circuit = gen.random_1q_cx_circuit(n, depth=args.depth)
+    n_gates = len(circuit["gates"])
+    engine = make_engine(n, world, rank, local_rank, mode=args.mode)
+    engine.init_zero_state()
+    plan = engine.plan(circuit, repeats=args.warmup + args.steps)
+    for _ in range(args.warmup):
+        engine.execute(plan)
+    engine.barrier()
+    engine.reset_comm_stats()
     engine.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -161,71 +299,89 @@ def main():
     prof = engine.profile_end()
     dt = engine.max_over_ranks(dt_local)
     norm2 = engine.norm2()
+    xgmi = engine.comm_stats()
+    passes = engine.passes_per_step(plan)
+    if abs(norm2 - 1.0) > NORM_TOL:
+        invalid.append(f"|norm2 - 1| = {abs(norm2 - 1.0):.3e} > {NORM_TOL}")
 
+    configs = None
+    if not args.no_configs:
+        configs = engine.run_baseline_configs(gen)          # config 4 staged / unstaged, config 5 closed forms
+        for rec in configs.get("config5", []):
+            if not rec["max_abs_err_vs_closed_form"] < PARITY_TOL:
+                invalid.append(f"config 5 {rec['circuit']}: max error {rec['max_abs_err_vs_closed_form']:.3e}")
+        c4 = configs.get("config4")
+        if c4 and abs(c4["staged"]["norm2"] - 1.0) > NORM_TOL:
+            invalid.append("config 4: norm check failed")
     if rank != 0:
         engine.close()
-        return
+        return None, invalid
 
-    shard_gate_apps = n_gates * world * args.steps
-    value = shard_gate_apps / dt
     dom = max(prof, key=lambda e: e["total_ms"]) if prof else None
     roofline = None
     if dom:
         secs = dom["total_ms"] * 1e-3
-        achieved = dom["algorithmic_bytes"] / secs / 1e9
         moved = dom["hbm_bytes"] / secs / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic_per_launch(dom["kernel"].split(" ")[0]),
+        roofline = {"bound": "hbm", "achieved": round(moved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(moved / HBM_PEAK_GBS, 4), "traffic": None,
                     "kernel": dom["kernel"], "launches": dom["launches"],
                     "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4),
-                    "algorithmic_bytes_per_launch": dom["algorithmic_bytes"] / dom["launches"],
-                    "hbm_bytes_moved_per_launch": dom["hbm_bytes"] / dom["launches"],
-                    "hbm_GBps_moved": round(moved, 1), "hbm_frac_moved": round(moved / HBM_PEAK_GBS, 4),
-                    "note": "achieved = algorithmic bytes (SURVEY 8d, summed over the gate-applications a "
-                            "launch performs) / HIP-event time; a fused pass applies many gates per HBM "
-                            "round trip, so achieved may exceed the physical peak; hbm_*_moved is what "
-                            "the launch itself reads+writes (32 B per amplitude)"}
-    total_moved = sum(e["hbm_bytes"] for e in prof)
+                    "bytes_per_launch": dom["hbm_bytes"] / dom["launches"],
+                    "algorithmic_GBps": round(dom["algorithmic_bytes"] / secs / 1e9, 1),
+                    "note": "rank 0's launches; achieved = bytes a launch reads+writes on its shard / HIP-event time"}
     out = {
         "metric": "gate-applications/sec (random 1q+CX circuit, complex128 statevector)",
-        "value": round(value, 2), "unit": "gate-applications/s",
+        "value": round(n_gates * args.steps / dt, 2), "unit": "gate-applications/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{n}-qubit random 1q+CX circuit depth {args.depth} (seed 20260228), "
-                               f"{n_gates} gates, complex128, {k} local qubits per GPU",
+                               f"{n_gates} gates, complex128, {k} local qubits per GPU, shards = high qubits",
                    "n_qubits": n, "local_qubits": k, "gates_per_step": n_gates, "mode": args.mode,
-                   "hbm_passes_per_step": engine.passes_per_step(plan),
-                   "unit_note": "value = shard-level gate applications (gate x rank) per second"},
-        "global_gate_apps_per_s": round(n_gates * args.steps / dt, 2),
-        "hbm_GBps_moved_all_kernels_per_gpu": round(total_moved / dt / 1e9, 1),
+                   "hbm_passes_per_step": passes,
+                   "unit_note": "value = gates of the circuit applied to the WHOLE 2^n state per second (the same "
+                                "unit at every N; per-GPU shard work is fixed, so this is weak scaling)"},
+        "timed_seconds": round(dt, 4),
+        "shard_gate_apps_per_s": round(n_gates * world * args.steps / dt, 2),
         "norm2_after": norm2,
         "roofline": roofline,
+        "xgmi": xgmi,
         "kernel_breakdown": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof],
+        "baseline_configs": configs,
     }
-    if world > 1:
-        out["xgmi"] = engine.comm_stats()
-    if not args.no_sweep and world == 1:
-        # BASELINE config 3 / north-star target: H on every target of a 30-qubit state, per-gate
-        # kernels (no fusion across the timed gates), fraction of the 8 TB/s peak per target
-        out["sweep30"] = engine.sweep_1q(args.sweep_qubits)
-        sw = out["sweep30"]
-        out["roofline_per_gate_kernel"] = {
-            "bound": "hbm", "kernel": "k_gate<2> / k_gate_shuffle<1,1>: dense 1q, one launch per gate",
-            "achieved": round(sw["median_frac"] * HBM_PEAK_GBS, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": sw["median_frac"], "min_frac_over_targets": sw["min_frac"],
-            "workload": f"H on every target of a {sw['n_qubits']}-qubit state (32 B x 2^n per launch)"}
-    if not args.no_cpu_baseline and world == 1:
-        base, psi_cpu, done = cpu_baseline(circuit, args.cpu_seconds)
-        out["cpu_baseline"] = base
-        # parity of the same prefix on the GPU (outside every timed region)
-        out["parity_max_abs_diff_vs_cpu_prefix"] = engine.prefix_parity(circuit, done, psi_cpu)
-        del psi_cpu
-        out["cpu_baseline_v1_sql"] = cpu_v1_sql_baseline()
     engine.close()
-    print(json.dumps(out), flush=True)
+    return out, invalid
+
+
+def main():
+    args = parse_args()
+    refuse_probe_environment()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if world & (world - 1):
+        raise SystemExit("number of GPUs must be a power of two (shards are indexed by high qubits)")
+    k = args.local_qubits or (28 if world == 1 else 30)
+
+    if args.dry_run:
+        from quantum_simulations_amd.runner.dry_run import main as dry_main
+        sys.exit(dry_main(world, rank, k))
+
+    if world == 1:
+        out, invalid = run_single(args, k)
+    else:
+        out, invalid = run_multi(args, world, rank, local_rank, k)
+    if out is not None:
+        if invalid:
+            out["invalid"] = invalid
+        print(json.dumps(out), flush=True)
+    if invalid:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@ block (tile_kernel.h, `TileArgs::stream`):
 Fixed registers (listed as clobbers of the asm statement):
   v[4:35]   x0..x7 (complex128 each: .x = v[4+4j:5+4j], .y = v[6+4j:7+4j])
   v[36:43]  LDS byte addresses of x0..x7      v44 tb (thread's tile index with the group bits 0)
-  v45 scratch   v46 tid   v[48:71] twelve f64 temporaries
+  v45 scratch   v46 tid   v[48:63] eight f64 temporaries
   s[16:17] scratch pair  s18 scratch  s19 base >> 3 (outer predicate)
   s[20:21] / s[22:23] branch-table base of bank A / B   s[24:25] jump target
   s[26:27] kernel-argument pointer   s[28:29] mask of live lanes (tiles smaller than 8 x blockDim)
@@ -116,7 +116,7 @@ def chunks(seq, n):
 def body_real(a, bank, pairs):
     """x_a' = r00 x_a + r01 x_b, x_b' = r10 x_a + r11 x_b (real entries r00,r01,r10,r11 = doubles 0..3)"""
     r00, r01, r10, r11 = (M(bank, k) for k in range(4))
-    for grp in chunks(pairs, 3):
+    for grp in chunks(pairs, 2):
         for i, (pa, pb) in enumerate(grp):
             ax, ay, _ = X(pa)
             a(f"v_mul_f64 {T(4 * i)}, {r00}, {ax}")
@@ -217,7 +217,7 @@ def body_ylike(a, bank, pairs):
 
 def phase_ops(a, regs_and_u):
     """x *= u for a list of (register, (ux, uy)); u operands are SGPR or VGPR pairs"""
-    for grp in chunks(regs_and_u, 6):
+    for grp in chunks(regs_and_u, 4):
         for i, (r, (ux, uy)) in enumerate(grp):
             xx, xy, _ = X(r)
             a(f"v_mul_f64 {T(2 * i)}, {ux}, {xx}")
@@ -446,7 +446,7 @@ def engine(partial: bool) -> list[str]:
 
 
 def clobbers() -> str:
-    regs = [f"v{i}" for i in range(4, 72)] + [f"s{i}" for i in range(16, 32)] + [f"s{i}" for i in range(36, 84)] + ["vcc", "scc", "memory"]
+    regs = [f"v{i}" for i in range(4, 64)] + [f"s{i}" for i in range(16, 30)] + [f"s{i}" for i in range(36, 84)] + ["vcc", "scc", "memory"]
     return ", ".join(f'"{r}"' for r in regs)
 
 

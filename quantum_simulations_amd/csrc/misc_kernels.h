@@ -60,9 +60,12 @@ __global__ void k_scale(double2* p, u64 n, double s) {
   }
 }
 
+// NT: streaming (non-temporal) accesses for copies larger than the Infinity Cache -- the same cache
+// policy the gate kernels use; this copy is also bench.py's same-run device-to-device ceiling.
+template <bool NT>
 __global__ void k_copy(double2* __restrict__ dst, const double2* __restrict__ src, u64 n) {
   const u64 stride = (u64)gridDim.x * blockDim.x;
-  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) st_amp<NT>(dst + i, ld_amp<NT>(src + i));
 }
 
 // dst[j] = src[insert(j, bit, value)]  /  inverse

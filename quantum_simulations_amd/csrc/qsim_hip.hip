@@ -208,7 +208,10 @@ int qsim_copy(qsim_chunk* dst, const qsim_chunk* src) {
   if (dst->k != src->k) return fail(QSIM_ERR_INVALID, "qsim_copy: sizes differ");
   if (dst->amp == src->amp) return QSIM_OK;
   HIP_TRY(hipSetDevice(dst->device));
-  hipLaunchKernelGGL(k_copy, dim3(stream_grid(amps(dst))), dim3(kBlock), 0, dst->stream, dst->amp, src->amp, amps(dst));
+  if ((sizeof(double2) << dst->k) > tuning().mall_bytes)
+    hipLaunchKernelGGL((k_copy<true>), dim3(stream_grid(amps(dst))), dim3(kBlock), 0, dst->stream, dst->amp, src->amp, amps(dst));
+  else
+    hipLaunchKernelGGL((k_copy<false>), dim3(stream_grid(amps(dst))), dim3(kBlock), 0, dst->stream, dst->amp, src->amp, amps(dst));
   HIP_TRY(hipGetLastError());
   return QSIM_OK;
 }

@@ -80,7 +80,8 @@ struct TileArgs {
   double2* amp;
   int nrec;                // records in the stream incl. END (host bookkeeping; the device follows the stream)
   int T;                   // tile size of the pass (read by the pass-image consumers; the kernel is a template)
-  uint8_t h[16];           // ascending absolute positions of the tile's high bits
+  uint8_t h[12];           // ascending absolute positions of the tile's high bits
+  uint32_t ntiles;         // 2^(k - T): the resident grid walks the tiles with stride gridDim.x
   uint32_t stream[kTileStreamBytes / 4];
 };
 static_assert(sizeof(TileArgs) == kTileArgBytes, "kernel arguments are one 4 KiB block");
@@ -90,13 +91,28 @@ static_assert(offsetof(TileArgs, stream) == kTileStreamOff, "record offsets are 
 // conflicts are not what limits the gate phase).  Linear over GF(2): the engine relies on it.
 __host__ __device__ __forceinline__ unsigned lds_slot(unsigned t) { return t ^ ((t >> 4) & 15u); }
 
-// min waves per SIMD asked of the register allocator: what the LDS footprint admits, capped at 5
+// Build-time variants (A/B with tools/ab_libs.sh): resident grid that walks the tiles, and whether the
+// next tile's global loads are issued before the finished tile is stored (needs 64 data registers at once).
+#ifndef QSIM_TILE_PERSIST
+#define QSIM_TILE_PERSIST 0
+#endif
+#ifndef QSIM_TILE_PREFETCH
+#define QSIM_TILE_PREFETCH 0
+#endif
+#ifndef QSIM_TILE_WAVES
+#define QSIM_TILE_WAVES 5
+#endif
+// min waves per SIMD asked of the register allocator: what the LDS footprint admits, capped
 constexpr int tile_waves(int T) {
-  return (160 * 1024) / ((1 << T) * 16) > 5 ? 5 : (160 * 1024) / ((1 << T) * 16);
+  return (160 * 1024) / ((1 << T) * 16) > QSIM_TILE_WAVES ? QSIM_TILE_WAVES : (160 * 1024) / ((1 << T) * 16);
 }
 
-// One workgroup per tile (a resident grid that prefetched the next tile into registers during the
-// gate phase was measured twice and was never faster: 163 VGPRs -> 3 workgroups per CU).
+// One workgroup per tile.  Measured alternatives (profiles/r02b_ab_persist.txt, same device and session):
+// a resident grid walking the tiles with stride gridDim.x is 29 % SLOWER (2.47 vs 1.92 ms per pass: its
+// workgroups run their load / compute / store phases in lockstep, so HBM idles while they compute; freshly
+// dispatched workgroups stagger by themselves), and so is that grid with the next tile's loads issued
+// before the finished tile is stored (2.36 ms, 106 VGPRs -> 4 workgroups per CU).  Both stay selectable
+// at build time (QSIM_TILE_PERSIST / QSIM_TILE_PREFETCH) for A/B runs.
 template <int T, bool NT>
 __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const TileArgs a) {
   constexpr int N = 1 << T;
@@ -130,37 +146,57 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
     for (int i = TB - LOW; i < NH; ++i) o |= (u64)((j >> (i - (TB - LOW))) & 1) << a.h[i];
     return o;
   };
-  const u64 base = tile_base(blockIdx.x);
-  {
-    double2 v[PER];
+  const auto karg = __builtin_amdgcn_kernarg_segment_ptr();
+  unsigned tile = blockIdx.x;                         // (the host launches at most ntiles workgroups)
+  u64 base = tile_base(tile);
+  double2 v[PER];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) v[j] = ld_amp<NT>(a.amp + base + off_tid + off_j(j));
+  for (int j = 0; j < PER; ++j) v[j] = ld_amp<NT>(a.amp + base + off_tid + off_j(j));
+  for (;;) {
 #pragma unroll
     for (int j = 0; j < PER; ++j) lds[lds_slot(tid + BLOCK * j)] = v[j];
-  }
-  __syncthreads();
-  // ---- gate engine: interprets a.stream on the tile in LDS; returns after its last barrier ----
-  {
-    const unsigned baseh = __builtin_amdgcn_readfirstlane((unsigned)(base >> LOW));
-    const auto karg = __builtin_amdgcn_kernarg_segment_ptr();
-    if constexpr (NBLK == BLOCK) {
-      asm volatile(QS_ENGINE_ASM_FULL
-                   :
-                   : [tid] "v"(tid), [karg] "s"(karg), [baseh] "s"(baseh), [first] "i"(kTileStreamOff)
-                   : QS_ENGINE_CLOBBERS);
-    } else {
-      asm volatile(QS_ENGINE_ASM_PARTIAL
-                   :
-                   : [tid] "v"(tid), [karg] "s"(karg), [baseh] "s"(baseh), [first] "i"(kTileStreamOff), [nblk] "s"(NBLK)
-                   : QS_ENGINE_CLOBBERS);
+    __syncthreads();
+    // ---- gate engine: interprets a.stream on the tile in LDS; returns after its last barrier ----
+    {
+      const unsigned baseh = __builtin_amdgcn_readfirstlane((unsigned)(base >> LOW));
+      if constexpr (NBLK == BLOCK) {
+        asm volatile(QS_ENGINE_ASM_FULL
+                     :
+                     : [tid] "v"(tid), [karg] "s"(karg), [baseh] "s"(baseh), [first] "i"(kTileStreamOff)
+                     : QS_ENGINE_CLOBBERS);
+      } else {
+        asm volatile(QS_ENGINE_ASM_PARTIAL
+                     :
+                     : [tid] "v"(tid), [karg] "s"(karg), [baseh] "s"(baseh), [first] "i"(kTileStreamOff), [nblk] "s"(NBLK)
+                     : QS_ENGINE_CLOBBERS);
+      }
     }
-  }
-  {
     double2 w[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) w[j] = lds[lds_slot(tid + BLOCK * j)];
+    const u64 done_base = base;
+#if QSIM_TILE_PERSIST
+    tile += gridDim.x;
+    const bool more = tile < a.ntiles;                // uniform: every wave of the grid leaves the loop
+#else
+    const bool more = false;
+#endif
+#if QSIM_TILE_PREFETCH
+    if (more) {
+      base = tile_base(tile);
 #pragma unroll
-    for (int j = 0; j < PER; ++j) st_amp<NT>(a.amp + base + off_tid + off_j(j), w[j]);
+      for (int j = 0; j < PER; ++j) v[j] = ld_amp<NT>(a.amp + base + off_tid + off_j(j));
+    }
+#endif
+#pragma unroll
+    for (int j = 0; j < PER; ++j) st_amp<NT>(a.amp + done_base + off_tid + off_j(j), w[j]);
+    if (!more) break;
+#if !QSIM_TILE_PREFETCH
+    base = tile_base(tile);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) v[j] = ld_amp<NT>(a.amp + base + off_tid + off_j(j));
+#endif
+    __syncthreads();                                  // every wave has read its part of the finished tile
   }
 }
 

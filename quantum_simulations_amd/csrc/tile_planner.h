@@ -91,11 +91,23 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
     return fail(QSIM_ERR_INVALID, "internal: tile size %d not built", T);
   } else {
   const u64 ntiles = 1ull << (c->k - T);
+  if (ntiles > 0xFFFFFFFFull) return fail(QSIM_ERR_INVALID, "internal: too many tiles");
+  TileArgs args = a;
+  args.ntiles = (uint32_t)ntiles;
+  // resident grid: what the device holds at once (LDS: 160 KiB / tile bytes, at most 8 workgroups of
+  // 4 waves per CU), never more workgroups than tiles
+  static int n_cu = 0;
+  if (!n_cu) {
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  const int per_cu = std::min(8, (160 * 1024) / ((1 << T) * 16));
+  const unsigned grid = QSIM_TILE_PERSIST ? (unsigned)std::min<u64>(ntiles, (u64)n_cu * std::min(per_cu, QSIM_TILE_WAVES)) : (unsigned)ntiles;
   ProfileScope prof(6, alg_bytes, stream, 32.0 * (double)amps(c));
   bool nt = c->span_bytes > tuning().mall_bytes;       // cache policy by state size (gate_plan.h)
   if (tuning().force_nt >= 0) nt = tuning().force_nt != 0;
-  if (nt) hipLaunchKernelGGL((k_tile<T, true>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a);
-  else hipLaunchKernelGGL((k_tile<T, false>), dim3((unsigned)ntiles), dim3(kTileThreads), 0, stream, a);
+  if (nt) hipLaunchKernelGGL((k_tile<T, true>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+  else hipLaunchKernelGGL((k_tile<T, false>), dim3(grid), dim3(kTileThreads), 0, stream, args);
   prof.done(stream);
   HIP_TRY(hipGetLastError());
   return QSIM_OK;

@@ -82,29 +82,63 @@ class SingleGpuEngine:
     def profile_end(self) -> list[dict]:
         return self.state.profile_end()
 
-    def sweep_1q(self, n: int, reps: int = 5) -> dict:
-        """BASELINE config 3: H on every target of an n-qubit random state, per-target
-        HIP-event timing, as fractions of the 8 TB/s HBM peak (32 * 2^n bytes per gate)."""
+    def sweep_gates(self, n: int, reps: int = 5) -> dict:
+        """BASELINE config 3: one gate per launch on an n-qubit random state, per-target HIP-event
+        timing (median of `reps`), as fractions of the 8 TB/s HBM peak of SURVEY 8d's algorithmic bytes:
+        H(q) 32 * 2^n for every q; secondary rows T(q), CNOT(q, q+1), CNOT(0, q) at 16 * 2^n."""
         dev = self.state if n == self.n else DeviceChunk.empty(n, self.state.device)
         dev.init_random(30)
-        H = gate_table.H()
-        per_target = []
-        for q in range(n):
-            dev.apply_1q(q, H)
+        H, T, CX = gate_table.H(), gate_table.T(), gate_table.CNOT()
+        N = 1 << n
+
+        def timed(fn) -> float:
+            fn()
             dev.sync()
             ts = []
             for _ in range(reps):
                 dev.time_begin()
-                dev.apply_1q(q, H)
+                fn()
                 ts.append(dev.time_end())
-            per_target.append(float(np.median(ts)))
-        fr = [32.0 * (1 << n) / (ms * 1e-3) / 8.0e12 for ms in per_target]
+            return float(np.median(ts))
+
+        def row(label, targets, fn, nbytes, note=None) -> dict:
+            ms = [timed(lambda q=q: fn(q)) for q in targets]
+            fr = [nbytes / (t * 1e-3) / 8.0e12 for t in ms]
+            out = {"targets": [int(q) for q in targets], "algorithmic_bytes_per_gate": nbytes,
+                   "ms_per_target": [round(t, 4) for t in ms], "frac_of_8TBps": [round(f, 4) for f in fr],
+                   "min_frac": round(min(fr), 4), "median_frac": round(float(np.median(fr)), 4),
+                   "max_frac": round(max(fr), 4), "gate_apps_per_s_median": round(1e3 / float(np.median(ms)), 1)}
+            if note:
+                out["note"] = note
+            return out
+
+        subline = ("a diagonal / control bit below index bit 3 shares every 128-B line with the untouched half: every "
+                   "line must move, so the algorithmic fraction of those targets is capped near 0.37 by construction")
+        rows = {"H(q)": row("H", range(n), lambda q: dev.apply_1q(q, H), 32 * N),
+                "T(q)": row("T", range(n), lambda q: dev.apply_1q(q, T), 16 * N, subline),
+                "CNOT(q,q+1)": row("CX", range(n - 1), lambda q: dev.apply_2q(q, q + 1, CX), 16 * N, subline),
+                "CNOT(0,q)": row("CX0", range(1, n), lambda q: dev.apply_2q(0, q, CX), 16 * N, subline)}
+        norm2 = dev.norm2()
         if dev is not self.state:
             dev.close()
-        return {"n_qubits": n, "gate": "H", "ms_per_target": [round(t, 4) for t in per_target],
-                "frac_of_8TBps": [round(f, 4) for f in fr], "min_frac": round(min(fr), 4),
-                "median_frac": round(float(np.median(fr)), 4),
-                "gate_apps_per_s_median": round(1e3 / float(np.median(per_target)), 1)}
+        return {"n_qubits": n, "reps": reps, "rows": rows, "norm2_after": norm2}
+
+    def copy_ceiling(self, reps: int = 7) -> dict:
+        """Same-run device-to-device copy of a buffer of the state's size (qsim_copy: streaming loads and
+        stores, 32 B moved per amplitude): the practical HBM ceiling next to the nominal 8 TB/s."""
+        other = DeviceChunk.empty(self.n, self.state.device)
+        other.copy_from(self.state)
+        other.sync()
+        ts = []
+        for _ in range(reps):
+            other.time_begin()
+            other.copy_from(self.state)
+            ts.append(other.time_end())
+        other.close()
+        ms = float(np.median(ts))
+        gbps = 32.0 * (1 << self.n) / (ms * 1e-3) / 1e9
+        return {"GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4), "ms": round(ms, 4),
+                "bytes": 32 * (1 << self.n), "kernel": "k_copy (read + write, non-temporal above 256 MiB)"}
 
     def prefix_parity(self, circuit_dict: dict, n_gates: int, expected: np.ndarray) -> float:
         """max |amp - expected| after the first n_gates gates from |0..0> (checker hook for

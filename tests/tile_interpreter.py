@@ -20,7 +20,7 @@ STREAM_OFF = 32                    # byte offset of the first record (csrc/tile_
 OPC = dict(DENSE1=1, SWAP1=10, ANTI1=19, PHASE=28, DENSE2=36, REAL1=45, YLIKE1=54, PHASE_NEG=63,
            PHASE_I=71, PHASE_NI=79, DIAGR=87, PRED_OUTER=91, PRED_LANE=92, GROUP=93, GROUP_FIRST=94, END=95)
 _FAMILIES = ("DENSE1", "SWAP1", "ANTI1", "PHASE", "DENSE2", "REAL1", "YLIKE1", "PHASE_NEG", "PHASE_I", "PHASE_NI", "DIAGR")
-_IMAGE = np.dtype([("amp", "<u8"), ("nrec", "<i4"), ("T", "<i4"), ("h", "u1", (16,)),
+_IMAGE = np.dtype([("amp", "<u8"), ("nrec", "<i4"), ("T", "<i4"), ("h", "u1", (12,)), ("ntiles", "<u4"),
                    ("stream", "u1", (IMAGE_BYTES - STREAM_OFF,))])
 assert _IMAGE.itemsize == IMAGE_BYTES
 
