@@ -123,10 +123,48 @@ int qsim_unpack_all(qsim_chunk* dst, int m, const int32_t* bits, const qsim_chun
 
 /* All-to-all re-layout among the 2^g chunks of ONE device (chunks[c] = chunk index c): swaps
  * local qubit local_bits[i] with chunk-index bit global_bits[i] for i < m (m <= 3) -- the merged
- * form of a staging SWAP list ([p_out < k, p_in >= k], SWAP), staging.py:136-152.  Across GPUs
- * the same exchange is driven by runner/distributed.py with qsim_pack_bits / RCCL.           */
+ * form of a staging SWAP list ([p_out < k, p_in >= k], SWAP), staging.py:136-152.  Across GPUs:
+ * qsim_comm_relayout below (the Python runner drives the same kernels over its own process group). */
 int qsim_swap_global_local(qsim_chunk* const* chunks, int n_chunks, const int32_t* global_bits,
                            const int32_t* local_bits, int m);
+
+/* ---- multi-GPU reach: RCCL (xGMI) inside the library --------------------------------------------
+ * One process per GPU, shard g = amplitudes [g * 2^k, (g+1) * 2^k) (the reference's chunk g,
+ * block_store.py:14-15), so a gate on qubit q >= k pairs rank g with g XOR 2^(q-k) exactly like the
+ * partner chunks of cpu_nonlocal.py:7-15 / single_node.py:271-321.  Rank 0 makes a unique id and the host
+ * program hands the 128 bytes to the other ranks (any transport); every rank then creates its
+ * communicator.  RCCL is loaded with dlopen at the first of these calls: the rest of the ABI works
+ * without it.  All calls are enqueued on the chunks' stream (qsim_sync to wait).                   */
+#define QSIM_COMM_ID_BYTES 128
+typedef struct qsim_comm qsim_comm;
+int qsim_comm_get_unique_id(uint8_t id[QSIM_COMM_ID_BYTES]);
+int qsim_comm_init(int device, int rank, int world, const uint8_t id[QSIM_COMM_ID_BYTES], qsim_comm** out);
+int qsim_comm_destroy(qsim_comm* comm);
+int qsim_comm_rank(const qsim_comm* comm);
+int qsim_comm_world(const qsim_comm* comm);
+/* One grouped exchange: for every i < n_peers send `count_amps` amplitudes of `send` starting at
+ * send_off[i] to rank peers[i] and receive as many from it into `recv` at recv_off[i].            */
+int qsim_comm_exchange(qsim_comm* comm, int n_peers, const int32_t* peers, const qsim_chunk* send,
+                       const uint64_t* send_off, qsim_chunk* recv, const uint64_t* recv_off, uint64_t count_amps);
+/* qsim_swap_global_local ACROSS GPUs: local qubit local_bits[i] of this rank's shard trades places
+ * with rank bit global_bits[i] (qubit k + global_bits[i]) for i < m <= 3 -- the merged all-to-all form
+ * of a staging SWAP list (staging.py:136-152).  Every rank of the communicator calls it with the same
+ * arguments.  buf0 / buf1: two exchange buffers of the shard's size.  Packing, the RCCL exchange with
+ * the 2^m - 1 peers (all links at once) and unpacking are pipelined over n_pieces (1, 2, 4, 8) sub-ranges.
+ * (1 - 2^-m) of a shard crosses the links per rank.                                                */
+int qsim_comm_relayout(qsim_comm* comm, qsim_chunk* state, qsim_chunk* buf0, qsim_chunk* buf1, int m,
+                       const int32_t* local_bits, const int32_t* global_bits, int n_pieces);
+/* cpu_nonlocal.apply_1q_pair / apply_2q_pair_qa_local / apply_2q_pair_qb_local (cpu_nonlocal.py:22-58)
+ * with the partner chunk on rank `partner_rank` (both ranks call, naming each other): the partner's
+ * shard is received into `buf` and this rank's shard is updated.  my_side = this rank's value of the
+ * global qubit: 0 -> the shard is c0, 1 -> it is c1.  One shard crosses one xGMI link each way; a host
+ * that may change the qubit layout uses qsim_comm_relayout with m = 1 instead (half a shard, no return). */
+int qsim_apply_1q_pair_remote(qsim_comm* comm, qsim_chunk* shard, qsim_chunk* buf, int partner_rank, int my_side,
+                              const double U[8]);
+int qsim_apply_2q_pair_qa_local_remote(qsim_comm* comm, qsim_chunk* shard, qsim_chunk* buf, int partner_rank,
+                                       int my_side, int qa, const double U[32]);
+int qsim_apply_2q_pair_qb_local_remote(qsim_comm* comm, qsim_chunk* shard, qsim_chunk* buf, int partner_rank,
+                                       int my_side, int qb, const double U[32]);
 
 /* ---- synchronisation, reductions, timing ------------------------------------------- */
 int qsim_sync(qsim_chunk* c);

@@ -64,6 +64,16 @@ SIGNATURES = {
     "qsim_pack_all": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int]),
     "qsim_unpack_all": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int]),
     "qsim_swap_global_local": (C.c_int, [_P, C.c_int, _P, _P, C.c_int]),
+    "qsim_comm_get_unique_id": (C.c_int, [_P]),
+    "qsim_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P)]),
+    "qsim_comm_destroy": (C.c_int, [_P]),
+    "qsim_comm_rank": (C.c_int, [_P]),
+    "qsim_comm_world": (C.c_int, [_P]),
+    "qsim_comm_exchange": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_uint64]),
+    "qsim_comm_relayout": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int]),
+    "qsim_apply_1q_pair_remote": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
+    "qsim_apply_2q_pair_qa_local_remote": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "qsim_apply_2q_pair_qb_local_remote": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "qsim_sync": (C.c_int, [_P]),
     "qsim_norm2": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "qsim_max_abs_err_closed_form": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64,

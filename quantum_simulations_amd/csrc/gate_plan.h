@@ -28,6 +28,9 @@ static inline bool is_one(double re, double im) { return re == 1.0 && im == 0.0;
 constexpr int kLaneCut = 3;
 
 // Tunables (environment overrides are for profiling sweeps only).
+#ifndef QSIM_TILE_HAD_DEFAULT
+#define QSIM_TILE_HAD_DEFAULT 1
+#endif
 struct Tuning {
   int swz_cut = 64;   // XCD-contiguous block order when the highest removed bit is below this (r01 scan: always)
   int force_nt = -1;  // -1 auto, 0 never, 1 always
@@ -36,6 +39,7 @@ struct Tuning {
   int plan_lookahead = -1;   // tile-bit look-ahead of the pass builder: -1 auto (>= 24 qubits; two passes deep from 26), 0 off, 1 on, 2 two deep
   int tile_special = 1;      // real / Y-like / -1 / +-i special-case opcodes in fused passes
   int tile_merge_diag = 1;   // merge phase gates that share their predicate (OPC_DIAGR)
+  int tile_had = QSIM_TILE_HAD_DEFAULT;          // uncontrolled c [[1,1],[1,-1]] as add/sub butterflies + one scale per pass (OPC_HAD1 / OPC_SCALE)
   int debug_skip_gates = 0;  // probe build only: QSIM_DEBUG_SKIP_GATES=1: tile passes move data but apply nothing (WRONG results)
   int debug_stats = 0;       // QSIM_DEBUG_STATS=1: print gates / groups per pass to stderr
   // States up to this size stay in the 256 MiB Infinity Cache between launches when accessed with
@@ -49,6 +53,7 @@ struct Tuning {
     if (const char* e = getenv("QSIM_PLAN_LOOKAHEAD")) plan_lookahead = atoi(e);
     if (const char* e = getenv("QSIM_TILE_SPECIAL")) tile_special = atoi(e);
     if (const char* e = getenv("QSIM_TILE_MERGE_DIAG")) tile_merge_diag = atoi(e);
+    if (const char* e = getenv("QSIM_TILE_HAD")) tile_had = atoi(e);
 #ifdef QSIM_PROBES
     // Probe knobs (cache policy, launch shapes, gate-less passes that give WRONG results): only in the
     // probe build `make probes` -> libqsim_hip_probes.so that tools/ loads; the product library has none.

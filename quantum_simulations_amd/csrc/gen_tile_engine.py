@@ -37,13 +37,18 @@ Run:  python3 gen_tile_engine.py > tile_engine_gen.h      (the Makefile does; th
 """
 from __future__ import annotations
 
+import os
 import sys
+
+# Generation-time variants (A/B builds): QS_GEN_TAILS=1 ends every gate body with the fetch + dispatch
+# of the next record instead of a branch to the shared copy of that sequence.
+TAILS = os.environ.get("QS_GEN_TAILS", "0") == "1"
 
 # ---- entry numbers (header dword 0 = 4 * entry); the gate families keep the r01 opcode numbers ----
 OPC = dict(NOP=0, DENSE1=1, SWAP1=10, ANTI1=19, PHASE=28, DENSE2=36, REAL1=45, YLIKE1=54,
            PHASE_NEG=63, PHASE_I=71, PHASE_NI=79, DIAGR=87,
-           PRED_OUTER=91, PRED_LANE=92, GROUP=93, GROUP_FIRST=94, END=95)
-NENT = 96
+           PRED_OUTER=91, PRED_LANE=92, GROUP=93, GROUP_FIRST=94, END=95, HAD1=96, SCALE=105)
+NENT = 106
 
 BANK = {"A": 36, "B": 52}                # s32 (the ABI stack pointer) is reserved: banks start at s36
 E = 68                                   # overflow bank s[68:83]
@@ -130,6 +135,29 @@ def body_real(a, bank, pairs):
             a(f"v_fma_f64 {ay}, {r01}, {by}, {T(4 * i + 1)}")
             a(f"v_fma_f64 {bx}, {r11}, {bx}, {T(4 * i + 2)}")
             a(f"v_fma_f64 {by}, {r11}, {by}, {T(4 * i + 3)}")
+
+
+def body_had(a, bank, pairs):
+    """unscaled Hadamard butterfly x_a' = x_a + x_b, x_b' = x_a - x_b; the factor c of c [[1,1],[1,-1]] is
+    collected by the host over the pass and applied once (OPC_SCALE): b' = a - b, then a' = 2a - b'"""
+    for pa, pb in pairs:
+        ax, ay, _ = X(pa)
+        bx, by, _ = X(pb)
+        a(f"v_add_f64 {bx}, {ax}, -{bx}")
+        a(f"v_add_f64 {by}, {ay}, -{by}")
+    for pa, pb in pairs:
+        ax, ay, _ = X(pa)
+        bx, by, _ = X(pb)
+        a(f"v_fma_f64 {ax}, 2.0, {ax}, -{bx}")
+        a(f"v_fma_f64 {ay}, 2.0, {ay}, -{by}")
+
+
+def body_scale(a, bank):
+    """every amplitude of the tile times the real double 0 of the record"""
+    for r in range(8):
+        xx, xy, _ = X(r)
+        a(f"v_mul_f64 {xx}, {M(bank, 0)}, {xx}")
+        a(f"v_mul_f64 {xy}, {M(bank, 0)}, {xy}")
 
 
 def body_dense1(a, bank, pairs):
@@ -313,13 +341,14 @@ def gate_cases():
     """entry -> function(asm, bank) emitting the straight-line body"""
     cases = {}
     for fam, body in (("DENSE1", body_dense1), ("SWAP1", body_swap), ("ANTI1", body_anti), ("REAL1", body_real),
-                      ("YLIKE1", body_ylike)):
+                      ("YLIKE1", body_ylike), ("HAD1", body_had)):
         for var in range(9):
             cases[OPC[fam] + var] = (f"{fam.lower()}_{var}", lambda a, bank, body=body, var=var: body(a, bank, PAIRS[var]))
     for fam, body in (("PHASE", body_phase), ("PHASE_NEG", body_phase_neg), ("PHASE_I", body_phase_i),
                       ("PHASE_NI", body_phase_ni)):
         for var in range(8):
             cases[OPC[fam] + var] = (f"{fam.lower()}_{var}", lambda a, bank, body=body, var=var: body(a, bank, PHASE_REGS[var]))
+    cases[OPC["SCALE"]] = ("scale", body_scale)
     for var in range(4):
         cases[OPC["DIAGR"] + var] = (f"diagr_{var}", lambda a, bank, var=var: body_diagr(a, bank, var))
     for ja in range(3):
@@ -335,6 +364,23 @@ def dispatch(a, bank, off_reg):
     a(f"s_add_u32 s24, s{jb}, {off_reg}")
     a(f"s_addc_u32 s25, s{jb + 1}, 0")
     a("s_setpc_b64 s[24:25]")
+
+
+def top_sequence(a, bank):
+    """Record held in `bank` has arrived (after the wait): fetch the next one into the other bank, dispatch."""
+    nb = BANK[other(bank)]
+    a("s_mov_b64 exec, -1")
+    a("s_waitcnt lgkmcnt(0)")
+    a(f"s_load_dwordx16 s[{nb}:{nb + 15}], s[26:27], {HD(bank, 1)}")
+    dispatch(a, bank, HD(bank, 0))
+
+
+def next_record(a, bank):
+    """End of a gate body that ran from `bank`: go on with the record in the other bank."""
+    if TAILS:
+        top_sequence(a, other(bank))
+    else:
+        a(f"s_branch {lab('top_' + other(bank))}")
 
 
 def engine(partial: bool) -> list[str]:
@@ -375,10 +421,7 @@ def engine(partial: bool) -> list[str]:
         nb = BANK[other(bank)]
         # ---- top of a record held in `bank`: fetch the next one into the other bank, dispatch ----
         a.label("top_" + bank)
-        a("s_mov_b64 exec, -1")
-        a("s_waitcnt lgkmcnt(0)")
-        a(f"s_load_dwordx16 s[{nb}:{nb + 15}], s[26:27], {HD(bank, 1)}")
-        dispatch(a, bank, HD(bank, 0))
+        top_sequence(a, bank)
         # ---- predicates ----
         a.label("pred_lane_" + bank)
         a(f"s_and_b32 s18, {HD(bank, 2)}, s19")
@@ -430,7 +473,7 @@ def engine(partial: bool) -> list[str]:
             name, fn = cases[e]
             a.label(name + "_" + bank)
             fn(a, bank)
-            a(f"s_branch {lab('top_' + other(bank))}")
+            next_record(a, bank)
     # ---- end of the stream: last write-back; the tile is complete in LDS after the barrier ----
     a.label("end")
     if partial:

@@ -43,6 +43,7 @@ typedef unsigned long long u64;
 #include "tile_kernel.h"
 #include "tile_planner.h"
 #include "misc_kernels.h"
+#include "comm_rccl.h"
 
 // ------------------------------------------------------------------ C ABI
 extern "C" {
@@ -524,6 +525,156 @@ int qsim_swap_global_local(qsim_chunk* const* chunks, int n_chunks, const int32_
     }
   }
   return QSIM_OK;
+}
+
+// ---- multi-GPU reach of the C ABI (comm_rccl.h) ---------------------------------------------------
+int qsim_comm_get_unique_id(uint8_t id[QSIM_COMM_ID_BYTES]) {
+  static_assert(QSIM_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+  if (!id) return fail(QSIM_ERR_INVALID, "id is null");
+  int rc = rccl_load();
+  if (rc) return rc;
+  ncclUniqueId uid;
+  RCCL_TRY(g_rccl.GetUniqueId(&uid));
+  std::memcpy(id, uid.internal, NCCL_UNIQUE_ID_BYTES);
+  return QSIM_OK;
+}
+
+int qsim_comm_init(int device, int rank, int world, const uint8_t id[QSIM_COMM_ID_BYTES], qsim_comm** out) {
+  if (!out || !id) return fail(QSIM_ERR_INVALID, "null argument");
+  if (world < 1 || (world & (world - 1)) || rank < 0 || rank >= world)
+    return fail(QSIM_ERR_INVALID, "qsim_comm_init: world %d must be a power of two and 0 <= rank %d < world", world, rank);
+  int rc = rccl_load();
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(device));
+  ncclUniqueId uid;
+  std::memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
+  ncclComm_t comm = nullptr;
+  RCCL_TRY(g_rccl.CommInitRank(&comm, world, uid, rank));
+  qsim_comm* c = new qsim_comm();
+  c->comm = comm; c->rank = rank; c->world = world; c->device = device;
+  c->xfer_stream = nullptr;
+  for (auto& e : c->ev) e = nullptr;
+  *out = c;
+  return QSIM_OK;
+}
+
+int qsim_comm_destroy(qsim_comm* c) {
+  if (!c) return QSIM_OK;
+  (void)hipSetDevice(c->device);
+  if (c->xfer_stream) { (void)hipStreamSynchronize(c->xfer_stream); (void)hipStreamDestroy(c->xfer_stream); }
+  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  delete c;
+  return QSIM_OK;
+}
+
+int qsim_comm_rank(const qsim_comm* c) { return c ? c->rank : -1; }
+int qsim_comm_world(const qsim_comm* c) { return c ? c->world : -1; }
+
+int qsim_comm_exchange(qsim_comm* cm, int n_peers, const int32_t* peers, const qsim_chunk* send, const uint64_t* send_off,
+                       qsim_chunk* recv, const uint64_t* recv_off, uint64_t count_amps) {
+  int rc = check_comm(cm, "qsim_comm_exchange");
+  if (rc || (rc = check_chunk(send, "qsim_comm_exchange")) || (rc = check_chunk(recv, "qsim_comm_exchange"))) return rc;
+  if (n_peers < 0 || (n_peers && (!peers || !send_off || !recv_off))) return fail(QSIM_ERR_INVALID, "qsim_comm_exchange: bad peer list");
+  if (send->amp == recv->amp) return fail(QSIM_ERR_INVALID, "qsim_comm_exchange: send and receive chunks must differ");
+  for (int i = 0; i < n_peers; ++i) {
+    if (peers[i] < 0 || peers[i] >= cm->world) return fail(QSIM_ERR_INVALID, "qsim_comm_exchange: peer %d out of range", peers[i]);
+    if (send_off[i] > amps(send) || count_amps > amps(send) - send_off[i] || recv_off[i] > amps(recv) || count_amps > amps(recv) - recv_off[i])
+      return fail(QSIM_ERR_INVALID, "qsim_comm_exchange: slice %d outside its chunk", i);
+  }
+  HIP_TRY(hipSetDevice(cm->device));
+  return comm_exchange(cm, n_peers, peers, send->amp, send_off, recv->amp, recv_off, count_amps, send->stream);
+}
+
+// All-to-all re-layout of THIS rank's shard: local bits `local_bits[i]` trade places with rank bits
+// `global_bits[i]` (bit g of the rank = qubit k + g).  buf0 / buf1: exchange buffers of the shard's size.
+int qsim_comm_relayout(qsim_comm* cm, qsim_chunk* state, qsim_chunk* buf0, qsim_chunk* buf1, int m,
+                       const int32_t* local_bits, const int32_t* global_bits, int n_pieces) {
+  int rc = check_comm(cm, "qsim_comm_relayout");
+  if (rc || (rc = check_chunk(state, "qsim_comm_relayout")) || (rc = check_chunk(buf0, "qsim_comm_relayout")) ||
+      (rc = check_chunk(buf1, "qsim_comm_relayout"))) return rc;
+  if (m < 1 || m > 3 || !local_bits || !global_bits) return fail(QSIM_ERR_INVALID, "qsim_comm_relayout: 1..3 qubit pairs expected, got %d", m);
+  if (buf0->k != state->k || buf1->k != state->k || buf0->amp == buf1->amp || buf0->amp == state->amp || buf1->amp == state->amp)
+    return fail(QSIM_ERR_INVALID, "qsim_comm_relayout: two distinct exchange buffers of the shard's size are needed");
+  int g_bits = 0;
+  while ((1 << g_bits) < cm->world) ++g_bits;
+  for (int i = 0; i < m; ++i) {
+    if (local_bits[i] < 0 || local_bits[i] >= state->k)
+      return fail(QSIM_ERR_NONLOCAL, "qsim_comm_relayout: local bit %d is non-local for 2^%d shards", local_bits[i], state->k);
+    if (global_bits[i] < 0 || global_bits[i] >= g_bits) return fail(QSIM_ERR_INVALID, "qsim_comm_relayout: rank bit %d out of range", global_bits[i]);
+    for (int j = 0; j < i; ++j)
+      if (local_bits[j] == local_bits[i] || global_bits[j] == global_bits[i]) return fail(QSIM_ERR_INVALID, "qsim_comm_relayout: repeated bit");
+  }
+  if (n_pieces != 1 && n_pieces != 2 && n_pieces != 4 && n_pieces != 8) return fail(QSIM_ERR_INVALID, "qsim_comm_relayout: n_pieces must be 1, 2, 4 or 8");
+  while (n_pieces > 1 && (state->k - m) - (31 - __builtin_clz((unsigned)n_pieces)) < 20) n_pieces >>= 1;   // pieces stay >= 2^20 amplitudes
+  if (state->k - m < 3) n_pieces = 1;
+  HIP_TRY(hipSetDevice(cm->device));
+  if (!cm->xfer_stream) HIP_TRY(hipStreamCreateWithFlags(&cm->xfer_stream, hipStreamNonBlocking));
+  for (auto& e : cm->ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  int mine = 0;
+  for (int i = 0; i < m; ++i) mine |= ((cm->rank >> global_bits[i]) & 1) << i;
+  int32_t peers[7];
+  uint64_t offs[7];
+  const u64 slab = 1ull << (state->k - m);
+  const u64 part = slab / (u64)n_pieces;
+  int n_peers = 0;
+  for (int d = 0; d < (1 << m); ++d) {
+    if (d == mine) continue;
+    int peer = cm->rank;
+    for (int i = 0; i < m; ++i) peer = (peer & ~(1 << global_bits[i])) | (((d >> i) & 1) << global_bits[i]);
+    peers[n_peers] = peer;
+    offs[n_peers] = (u64)d * slab;              // slab d of the send buffer goes to the rank whose pattern is d
+    ++n_peers;
+  }
+  // pipeline: pack piece s+1 (main stream) while piece s is on the links (transfer stream); unpack behind it
+  for (int s = 0; s < n_pieces; ++s) {
+    if ((rc = slabs_all(state, m, local_bits, buf0, mine, s, n_pieces, true, "qsim_comm_relayout"))) return rc;
+    HIP_TRY(hipEventRecord(cm->ev[2 * s], state->stream));
+    HIP_TRY(hipStreamWaitEvent(cm->xfer_stream, cm->ev[2 * s], 0));
+    uint64_t so[7];
+    for (int i = 0; i < n_peers; ++i) so[i] = offs[i] + (u64)s * part;
+    if ((rc = comm_exchange(cm, n_peers, peers, buf0->amp, so, buf1->amp, so, part, cm->xfer_stream))) return rc;
+    HIP_TRY(hipEventRecord(cm->ev[2 * s + 1], cm->xfer_stream));
+  }
+  for (int s = 0; s < n_pieces; ++s) {
+    HIP_TRY(hipStreamWaitEvent(state->stream, cm->ev[2 * s + 1], 0));
+    if ((rc = slabs_all(state, m, local_bits, buf1, mine, s, n_pieces, false, "qsim_comm_relayout"))) return rc;
+  }
+  return QSIM_OK;
+}
+
+// The reference's partner-chunk butterflies with the partner chunk on ANOTHER rank: both ranks call with each
+// other's rank; `my_side` = this rank's value of the global qubit (0: this shard is c0, 1: it is c1).  The
+// partner's whole shard is received into `buf` and the pair kernel updates this rank's shard (the copy in
+// `buf` is scratch afterwards).
+static int pair_remote(qsim_comm* cm, qsim_chunk* shard, qsim_chunk* buf, int partner, int my_side, const char* what) {
+  int rc = check_comm(cm, what);
+  if (rc || (rc = check_chunk(shard, what)) || (rc = check_chunk(buf, what))) return rc;
+  if (buf->k != shard->k || buf->amp == shard->amp) return fail(QSIM_ERR_INVALID, "%s: the receive buffer must be a distinct chunk of the shard's size", what);
+  if (partner < 0 || partner >= cm->world) return fail(QSIM_ERR_INVALID, "%s: partner rank %d out of range", what, partner);
+  if (my_side != 0 && my_side != 1) return fail(QSIM_ERR_INVALID, "%s: my_side must be 0 or 1", what);
+  HIP_TRY(hipSetDevice(cm->device));
+  const int32_t peer = partner;
+  const uint64_t zero = 0;
+  return comm_exchange(cm, 1, &peer, shard->amp, &zero, buf->amp, &zero, amps(shard), shard->stream);
+}
+
+int qsim_apply_1q_pair_remote(qsim_comm* cm, qsim_chunk* shard, qsim_chunk* buf, int partner_rank, int my_side, const double U[8]) {
+  int rc = pair_remote(cm, shard, buf, partner_rank, my_side, "qsim_apply_1q_pair_remote");
+  if (rc) return rc;
+  return my_side == 0 ? qsim_apply_1q_pair(shard, buf, U) : qsim_apply_1q_pair(buf, shard, U);
+}
+
+int qsim_apply_2q_pair_qa_local_remote(qsim_comm* cm, qsim_chunk* shard, qsim_chunk* buf, int partner_rank, int my_side, int qa, const double U[32]) {
+  int rc = pair_remote(cm, shard, buf, partner_rank, my_side, "qsim_apply_2q_pair_qa_local_remote");
+  if (rc) return rc;
+  return my_side == 0 ? qsim_apply_2q_pair_qa_local(shard, buf, qa, U) : qsim_apply_2q_pair_qa_local(buf, shard, qa, U);
+}
+
+int qsim_apply_2q_pair_qb_local_remote(qsim_comm* cm, qsim_chunk* shard, qsim_chunk* buf, int partner_rank, int my_side, int qb, const double U[32]) {
+  int rc = pair_remote(cm, shard, buf, partner_rank, my_side, "qsim_apply_2q_pair_qb_local_remote");
+  if (rc) return rc;
+  return my_side == 0 ? qsim_apply_2q_pair_qb_local(shard, buf, qb, U) : qsim_apply_2q_pair_qb_local(buf, shard, qb, U);
 }
 
 int qsim_sync(qsim_chunk* c) {

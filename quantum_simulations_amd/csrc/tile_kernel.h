@@ -54,7 +54,10 @@ enum : uint8_t {
   OPC_PRED_LANE = QS_ENT_PRED_LANE,   // gate with tile bits outside the register group that must be 1 (+ outer bits)
   OPC_GROUP = QS_ENT_GROUP,           // register-group change
   OPC_GROUP_FIRST = QS_ENT_GROUP_FIRST,
-  OPC_END = QS_ENT_END
+  OPC_END = QS_ENT_END,
+  OPC_HAD1 = QS_ENT_HAD1,             // +variant 0..2 (no control): a' = a + b, b' = a - b          H     (0)
+                                      // the factor c of c [[1,1],[1,-1]] is collected over the pass and applied by
+  OPC_SCALE = QS_ENT_SCALE            // every amplitude times a real factor (1 double), last record of the pass
 };
 // 1q variant: 0..2 = target register bit J, no register control; 3 + 2*J + k = control on the
 // k-th of the two other register bits (ascending)
@@ -218,7 +221,8 @@ static inline int desc_bytes(const TileDesc& d) { return desc_bytes(d.nd); }
 constexpr int kGroupRecordBytes = 48;
 constexpr int kEndRecordBytes = 16;
 // bytes available to group and gate records (END and the over-read slack are set aside)
-constexpr int kTileRecordBudget = kTileStreamBytes - kEndRecordBytes - kTileStreamSlack;
+constexpr int kScaleRecordBytes = 32;
+constexpr int kTileRecordBudget = kTileStreamBytes - kEndRecordBytes - kTileStreamSlack - kScaleRecordBytes;
 
 // Write the record stream of a pass.  The caller has kept the total inside kTileRecordBudget.
 static int serialize_pass(const std::vector<TileGroup>& groups, TileArgs* a) {
@@ -226,7 +230,7 @@ static int serialize_pass(const std::vector<TileGroup>& groups, TileArgs* a) {
   int off = kTileStreamOff;
   int nrec = 0;
   auto put32 = [&](int at, uint32_t v) { std::memcpy(base + at, &v, 4); };
-  auto room = [&](int bytes) { return off + bytes + kEndRecordBytes + kTileStreamSlack <= kTileArgBytes; };
+  auto room = [&](int bytes) { return off + bytes + kEndRecordBytes + kTileStreamSlack <= kTileArgBytes; };   // (the SCALE record is inside kTileRecordBudget's reserve)
   bool first = true;
   for (const TileGroup& g : groups) {
     if (!room(kGroupRecordBytes)) return fail(QSIM_ERR_INVALID, "internal: pass record stream overflow");

@@ -102,7 +102,11 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
     n_cu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
   const int per_cu = std::min(8, (160 * 1024) / ((1 << T) * 16));
+#if QSIM_TILE_PERSIST && defined(QSIM_TILE_PER_WG)
+  const unsigned grid = (unsigned)std::max<u64>(1, ntiles / QSIM_TILE_PER_WG);     // a few tiles per workgroup
+#else
   const unsigned grid = QSIM_TILE_PERSIST ? (unsigned)std::min<u64>(ntiles, (u64)n_cu * std::min(per_cu, QSIM_TILE_WAVES)) : (unsigned)ntiles;
+#endif
   ProfileScope prof(6, alg_bytes, stream, 32.0 * (double)amps(c));
   bool nt = c->span_bytes > tuning().mall_bytes;       // cache policy by state size (gate_plan.h)
   if (tuning().force_nt >= 0) nt = tuning().force_nt != 0;
@@ -148,7 +152,10 @@ static OpShape op_shape(const FusedOp& o) {
       return {OPC_PHASE, 2};
     case TG_ANTI1: return (sp && is(1, 0, -1) && is(2, 0, 1)) ? OpShape{OPC_YLIKE1, 0} : OpShape{OPC_ANTI1, 4};
     case TG_DENSE2: return {OPC_DENSE2, 32};
-    default:   // a real 2x2 (H, RY, G) needs four doubles instead of eight
+    default:   // a real 2x2 (H, RY, G) needs four doubles instead of eight; an uncontrolled c [[1,1],[1,-1]] none
+      if (sp && tuning().tile_had && o.control < 0 && o.m[0].y == 0 && o.m[1].y == 0 && o.m[2].y == 0 && o.m[3].y == 0 &&
+          o.m[0].x == o.m[1].x && o.m[0].x == o.m[2].x && o.m[0].x == -o.m[3].x && o.m[0].x != 0)
+        return {OPC_HAD1, 0};
       return (sp && o.m[0].y == 0 && o.m[1].y == 0 && o.m[2].y == 0 && o.m[3].y == 0) ? OpShape{OPC_REAL1, 4}
                                                                                         : OpShape{OPC_DENSE1, 8};
   }
@@ -159,6 +166,7 @@ static OpShape op_shape(const FusedOp& o) {
 // everything that depends on them wait for the next launch).
 static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_t>& members,
                         const std::vector<int>& high, int T, std::vector<TileGroup>* out, std::vector<char>* emitted) {
+  double pass_scale = 1.0;            // product of the factors of the pass's unscaled Hadamard butterflies (OPC_HAD1)
   const int low = kTileLow;
   auto tile_pos = [&](int b) -> int {
     if (b < low) return b;
@@ -304,7 +312,9 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
         const int J = reg_pos(tile_pos(o.target[0]));
         if (o.control >= 0) require_one(o.control);
         d.opcode = (uint8_t)(shape.family + opc_1q_variant(J, ctrl_reg));
-        if (shape.family == OPC_REAL1) {
+        if (shape.family == OPC_HAD1) {
+          pass_scale *= o.m[0].x;
+        } else if (shape.family == OPC_REAL1) {
           d.m[0] = o.m[0].x; d.m[1] = o.m[1].x; d.m[2] = o.m[2].x; d.m[3] = o.m[3].x; d.nd = 4;
         } else if (shape.family == OPC_ANTI1) {
           put(0, o.m[1]); put(1, o.m[2]); d.nd = 4;
@@ -324,6 +334,14 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
     if (!tg.gates.empty()) out->push_back(tg);
     else used -= kGroupRecordBytes;
     if (cut) break;                   // record budget exhausted inside the group
+  }
+  if (pass_scale != 1.0 && !out->empty()) {   // a global factor commutes with everything: once, at the end
+    TileDesc d;
+    std::memset(&d, 0, sizeof d);
+    d.opcode = OPC_SCALE;
+    d.m[0] = pass_scale;
+    d.nd = 1;
+    out->back().gates.push_back(d);
   }
 }
 

@@ -221,3 +221,65 @@ def device_count() -> int:
     n = C.c_int()
     _lib.check(_lib.load().qsim_device_count(C.byref(n)))
     return n.value
+
+
+class Comm:
+    """RCCL communicator inside libqsim_hip.so (include/qsim_hip.h, multi-GPU reach of the C ABI): one per
+    process / GPU.  `unique_id()` on rank 0, hand the 128 bytes to every rank, then `Comm(device, rank,
+    world, uid)`.  The Python runner (runner/distributed.py) uses torch.distributed instead; this wrapper
+    is what a host without torch binds."""
+
+    ID_BYTES = 128
+
+    def __init__(self, device: int, rank: int, world: int, uid: bytes):
+        if len(uid) != self.ID_BYTES:
+            raise ValueError("the unique id has 128 bytes")
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * self.ID_BYTES).from_buffer_copy(uid)
+        _lib.check(_lib.load().qsim_comm_init(device, rank, world, C.cast(buf, C.c_void_p), C.byref(self._h)))
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * Comm.ID_BYTES)()
+        _lib.check(_lib.load().qsim_comm_get_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def exchange(self, peers, send: DeviceChunk, send_off, recv: DeviceChunk, recv_off, count: int) -> None:
+        p = np.asarray(peers, dtype=np.int32)
+        so, ro = np.asarray(send_off, dtype=np.uint64), np.asarray(recv_off, dtype=np.uint64)
+        _lib.check(_lib.load().qsim_comm_exchange(self._h, len(p), p.ctypes.data_as(C.c_void_p), send._h,
+                                                  so.ctypes.data_as(C.c_void_p), recv._h,
+                                                  ro.ctypes.data_as(C.c_void_p), int(count)))
+
+    def relayout(self, state: DeviceChunk, buf0: DeviceChunk, buf1: DeviceChunk, local_bits, global_bits,
+                 n_pieces: int = 4) -> None:
+        lb, gb = np.asarray(local_bits, dtype=np.int32), np.asarray(global_bits, dtype=np.int32)
+        _lib.check(_lib.load().qsim_comm_relayout(self._h, state._h, buf0._h, buf1._h, len(lb),
+                                                  lb.ctypes.data_as(C.c_void_p), gb.ctypes.data_as(C.c_void_p),
+                                                  int(n_pieces)))
+
+    def apply_1q_pair_remote(self, shard: DeviceChunk, buf: DeviceChunk, partner: int, my_side: int, U) -> None:
+        m, p = _mat_ptr(U, 2)
+        _lib.check(_lib.load().qsim_apply_1q_pair_remote(self._h, shard._h, buf._h, int(partner), int(my_side), p))
+
+    def apply_2q_pair_qa_local_remote(self, shard, buf, partner: int, my_side: int, qa: int, U) -> None:
+        m, p = _mat_ptr(U, 4)
+        _lib.check(_lib.load().qsim_apply_2q_pair_qa_local_remote(self._h, shard._h, buf._h, int(partner),
+                                                                  int(my_side), int(qa), p))
+
+    def apply_2q_pair_qb_local_remote(self, shard, buf, partner: int, my_side: int, qb: int, U) -> None:
+        m, p = _mat_ptr(U, 4)
+        _lib.check(_lib.load().qsim_apply_2q_pair_qb_local_remote(self._h, shard._h, buf._h, int(partner),
+                                                                  int(my_side), int(qb), p))
+
+    def close(self) -> None:
+        if self._h is not None and self._h.value:
+            _lib.load().qsim_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -13,8 +13,12 @@ partitioner and the driver-side sequential partner-group loop (spark_runner.py:1
   controlled gate, global control ... ranks whose control bit is 1 apply the 1q gate (locally,
                                        or with one partner when the target is global too)
   (local ops produced by the two rows above are queued and fused into the next local pass)
-  other gates on a global qubit ..... full-shard exchange with the partner rank over one xGMI
-                                       link + the partner-chunk kernel (apply_*_pair semantics)
+  other gates on a global qubit ..... swap-and-stay: the global qubit trades places with a local one
+                                       that is not needed soon (HALF a shard over one xGMI link for one
+                                       global qubit, 3/4 over three links for two), the gate then runs
+                                       locally in the next fused pass and the layout change is tracked
+                                       (the arithmetic of cpu_nonlocal.py:22-67 / single_node.py:271-321
+                                       without shipping whole shards there and results back)
   staging SWAP lists ([p_out<k, p_in>=k], SWAP; staging.py:136-152) of one step are MERGED
   into ONE all-to-all re-layout: each rank packs 2^m - 1 slabs, exchanges them with 2^m - 1
   peers concurrently (all links busy) and unpacks in place.
@@ -98,22 +102,6 @@ class HipShardBackend:
     def apply_ops(self, ops) -> int:
         return self.chunk("state").apply_ops(ops)      # HBM passes (fused tile launches)
 
-    def apply_1q_pair(self, names, U) -> None:
-        from quantum_simulations_amd.kernel import gpu_nonlocal
-        gpu_nonlocal.apply_1q_pair(self.chunk(names[0]), self.chunk(names[1]), U)
-
-    def apply_2q_pair_qa_local(self, names, qa, U) -> None:
-        from quantum_simulations_amd.kernel import gpu_nonlocal
-        gpu_nonlocal.apply_2q_pair_qa_local(self.chunk(names[0]), self.chunk(names[1]), qa, U)
-
-    def apply_2q_pair_qb_local(self, names, qb, U) -> None:
-        from quantum_simulations_amd.kernel import gpu_nonlocal
-        gpu_nonlocal.apply_2q_pair_qb_local(self.chunk(names[0]), self.chunk(names[1]), qb, U)
-
-    def apply_2q_quad(self, names, U) -> None:
-        from quantum_simulations_amd.kernel import gpu_nonlocal
-        gpu_nonlocal.apply_2q_quad(*(self.chunk(n) for n in names), U)
-
     def pack_bits(self, bits, pattern: int, dst: str, dst_offset: int) -> None:
         self.chunk("state").pack_bits(bits, pattern, self.chunk(dst), dst_offset)
 
@@ -144,10 +132,71 @@ class HipShardBackend:
 
 
 class Plan:
-    """Step lists for successive executions (the staging layout carries over between them)."""
+    """Step lists for successive executions (the staging layout carries over between them).
+    `start_mappings[i]` is the planned layout execution i starts from; `execute` refuses a plan whose
+    next execution was planned for another layout than the engine's current one."""
 
-    def __init__(self, executions: list, mappings: list):
-        self.executions, self.mappings, self.cursor = executions, mappings, 0
+    def __init__(self, executions: list, mappings: list, start_mappings: list):
+        self.executions, self.mappings, self.start_mappings, self.cursor = executions, mappings, start_mappings, 0
+
+
+class _FakeTensor:
+    """Stand-in for a shard / exchange buffer in dry runs: knows its length, checks slice bounds."""
+    is_cuda = False
+
+    def __init__(self, n: int):
+        self.n = n
+
+    def __getitem__(self, sl):
+        start, stop, step = sl.indices(self.n) if isinstance(sl, slice) else (sl, sl + 1, 1)
+        if not isinstance(sl, slice) or step != 1 or (sl.start or 0) < 0 or (sl.stop is not None and sl.stop > self.n) or stop < start:
+            raise IndexError(f"slice {sl} outside a buffer of {self.n} elements")
+        return _FakeTensor(stop - start)
+
+    def numel(self) -> int:
+        return self.n
+
+    @staticmethod
+    def element_size() -> int:
+        return 8
+
+
+class DryBackend:
+    """No memory, no arithmetic: lets the engine run its communication schedule at full problem sizes
+    (bench.py --dry-run, tests); every transfer is recorded in DistributedEngine.trace instead of posted."""
+    dry = True
+
+    def __init__(self, k: int):
+        self.k = k
+        self.local_passes = 0
+
+    def tensor(self, name: str):
+        return _FakeTensor(2 << self.k)
+
+    def init_zero(self, set_amp0: bool) -> None:
+        pass
+
+    def sync(self) -> None:
+        pass
+
+    def apply_ops(self, ops) -> int:
+        self.local_passes += 1
+        return 1
+
+    def pack_all(self, bits, dst, skip_pattern, piece=0, n_pieces=1) -> None:
+        self._check(bits, piece, n_pieces)
+
+    def unpack_all(self, bits, src, skip_pattern, piece=0, n_pieces=1) -> None:
+        self._check(bits, piece, n_pieces)
+
+    def _check(self, bits, piece, n_pieces) -> None:
+        if not 1 <= len(bits) <= 3 or len(set(bits)) != len(bits) or any(not 0 <= b < self.k for b in bits):
+            raise ValueError(f"re-layout bits {bits} invalid for {self.k} local qubits")
+        if n_pieces not in (1, 2, 4, 8) or not 0 <= piece < n_pieces:
+            raise ValueError("bad piece")
+
+    def close(self) -> None:
+        pass
 
 
 class DistributedEngine:
@@ -179,7 +228,12 @@ class DistributedEngine:
             else:
                 dist.init_process_group("gloo", rank=rank, world_size=world)
         self.backend = backend if backend is not None else HipShardBackend(self.k, local_rank)
-        self.l2p = list(range(n_qubits))      # logical qubit -> physical index bit
+        self.dry = bool(getattr(self.backend, "dry", False))
+        self.trace: list | None = [] if self.dry else None     # dry runs: (kind, peer, sent, received) per posted transfer
+        self.l2p_planned = list(range(n_qubits))   # logical qubit -> physical index bit as the PLANS see it
+        self._dyn = list(range(n_qubits))          # planned physical bit -> actual physical bit (swap-and-stay moves)
+        self._flat: list = []                      # qubit lists of the running execution, in order (victim choice)
+        self._flat_pos = 0
         self.xgmi_bytes_sent = 0
         self.exchanges = 0
         self._comm_events: list = []
@@ -188,6 +242,12 @@ class DistributedEngine:
         self.relayout_pieces, self.min_piece_qubits = relayout_pieces, min_piece_qubits
         self._passes = self.last_passes = 0
         self._pending: list = []
+
+    # ---- layout ------------------------------------------------------------------------
+    @property
+    def l2p(self) -> list[int]:
+        """logical qubit -> ACTUAL physical index bit (planned layout composed with the dynamic moves)"""
+        return [self._dyn[p] for p in self.l2p_planned]
 
     # ---- helpers -----------------------------------------------------------------------
     def _rank_bit(self, phys_qubit: int) -> int:
@@ -200,6 +260,12 @@ class DistributedEngine:
         """Post [(peer, send_tensor, recv_tensor)] together, without waiting (RCCL: the transfer is
         ordered after everything already queued on the current stream)."""
         dist, torch = self.dist, self.torch
+        if self.dry:
+            for peer, send, recv in transfers:
+                self.trace.append((self._trace_kind, int(peer), send.numel() * send.element_size(),
+                                   recv.numel() * recv.element_size()))
+                self.xgmi_bytes_sent += send.numel() * send.element_size()
+            return ([], [])
         staged, ops = [], []
         host = dist.get_backend() == "gloo"
         for peer, send, recv in transfers:
@@ -221,6 +287,8 @@ class DistributedEngine:
             work.wait()
         for dev_t, host_t in staged:
             dev_t.copy_(host_t)
+
+    _trace_kind = "relayout"
 
     def _comm_timer(self, tensor):
         """Device-side time of an exchange (stream events, summed in comm_stats)."""
@@ -262,7 +330,8 @@ class DistributedEngine:
     def init_zero_state(self) -> None:
         self._pending = []
         self.backend.init_zero(self.rank == 0)
-        self.l2p = list(range(self.n))
+        self.l2p_planned = list(range(self.n))
+        self._dyn = list(range(self.n))
 
     def norm2(self) -> float:
         self._flush_local()
@@ -301,13 +370,14 @@ class DistributedEngine:
         cd = validate_circuit_dict(circuit_dict)
         if cd["number_of_qubits"] != self.n:
             raise ValueError(f"circuit has {cd['number_of_qubits']} qubits, engine has {self.n}")
-        executions, mappings = [], []
-        l2p = list(self.l2p)
+        executions, mappings, starts = [], [], []
+        l2p = list(self.l2p_planned)
         for _ in range(max(1, repeats)):
+            starts.append(list(l2p))
             steps, l2p = self._steps_from(cd, l2p)
             executions.append(steps)
             mappings.append(list(l2p))
-        return Plan(executions, mappings)
+        return Plan(executions, mappings, starts)
 
     def passes_per_step(self, plan: Plan) -> int:
         """HBM passes of the last executed circuit on this rank: fused tile launches of the local
@@ -321,17 +391,38 @@ class DistributedEngine:
         i = plan.cursor
         if i >= len(plan.executions):
             raise RuntimeError("plan exhausted: call engine.plan(circuit, repeats=K) with enough repeats")
+        if plan.start_mappings[i] != self.l2p_planned:
+            raise RuntimeError("this execution of the plan was planned for another qubit layout than the engine's "
+                               "current one (the state was re-initialised or another plan ran in between): re-plan")
         self._passes = 0
+        self._flat = [qs for step in plan.executions[i] for qs, _ in list(step["local_ops"]) + list(step["nonlocal_ops"])]
+        self._flat_pos = 0
         for step in plan.executions[i]:
             self.run_step(step)
         self._flush_local()
         self.last_passes = self._passes
-        self.l2p = list(plan.mappings[i])
+        self.l2p_planned = list(plan.mappings[i])
         plan.cursor = i + 1
 
+    def _actual(self, qs) -> list[int]:
+        return [self._dyn[q] for q in qs]
+
     def run_step(self, step: dict) -> None:
-        if step["local_ops"]:
-            ops, self._pending = self._pending + list(step["local_ops"]), []
+        """Ops carry PLANNED physical bits; swap-and-stay moves may have put a planned-local qubit on a
+        rank bit (and back), so every op is classified by where its qubits actually are."""
+        k = self.k
+        batch = []
+        for qs, U in step["local_ops"]:
+            aq = self._actual(qs)
+            if all(q < k for q in aq):
+                batch.append((aq, U))
+            else:                                   # a victim of an earlier move: the ops before it first
+                self._pending += batch
+                batch = []
+                self.apply_nonlocal(aq, U)
+            self._flat_pos += 1
+        if batch:
+            ops, self._pending = self._pending + batch, []
             self._passes += self.backend.apply_ops(ops) or 0
         ops = step["nonlocal_ops"]
         i = 0
@@ -339,22 +430,39 @@ class DistributedEngine:
             j = i
             group = []
             used: set[int] = set()
-            while j < len(ops) and self._is_relayout_swap(ops[j]) and used.isdisjoint(ops[j][0]):
-                group.append(ops[j][0])
-                used.update(ops[j][0])
+            while (j < len(ops) and len(group) < 3 and self._is_planned_swap(ops[j])
+                   and self._is_cross(self._actual(ops[j][0])) and used.isdisjoint(self._actual(ops[j][0]))):
+                group.append(self._actual(ops[j][0]))   # (at most 3 pairs: qsim_pack_all's slab patterns)
+                used.update(group[-1])
                 j += 1
             if group:
                 self.relayout(group)
                 self._passes += 2
+                self._flat_pos += j - i
                 i = j
+                continue
+            qs, U = ops[i]
+            if self._is_planned_swap(ops[i]):
+                # a planned SWAP whose qubits are on the same side now: nothing has to move -- the two
+                # planned positions trade their actual bits (later gates find the qubits where they are)
+                a, b = qs
+                self._dyn[a], self._dyn[b] = self._dyn[b], self._dyn[a]
             else:
-                self.apply_nonlocal(*ops[i])
-                i += 1
+                aq = self._actual(qs)
+                if all(q < k for q in aq):
+                    self._queue_local((aq, U))
+                else:
+                    self.apply_nonlocal(aq, U)
+            self._flat_pos += 1
+            i += 1
 
-    def _is_relayout_swap(self, op) -> bool:
+    def _is_cross(self, aq) -> bool:
+        return (aq[0] < self.k) != (aq[1] < self.k)
+
+    @staticmethod
+    def _is_planned_swap(op) -> bool:
         qs, U = op
-        return (len(qs) == 2 and (qs[0] < self.k) != (qs[1] < self.k) and U.shape == (4, 4)
-                and np.array_equal(U, _SWAP))
+        return len(qs) == 2 and U.shape == (4, 4) and np.array_equal(U, _SWAP)
 
     # -- all-to-all re-layout: swap m local bits with m global bits ------------------------------
     def relayout(self, pairs) -> None:
@@ -403,6 +511,7 @@ class DistributedEngine:
 
     # -- one gate with at least one global qubit ---------------------------------------------------
     def apply_nonlocal(self, qs, U) -> None:
+        """qs: ACTUAL physical bits, at least one >= k."""
         k = self.k
         if len(qs) == 1:
             q = qs[0]
@@ -411,9 +520,8 @@ class DistributedEngine:
                 if U[b, b] != 1:
                     self._scale(U[b, b])
                 return
-            self._exchange_full(self._partner(q))
-            names = ("state", "buf1") if b == 0 else ("buf1", "state")
-            self.backend.apply_1q_pair(names, U)
+            (v,) = self._bring_local([q], exclude=())
+            self._queue_local(([v], U))
             return
         qa, qb = qs
         a_glob, b_glob = qa >= k, qb >= k
@@ -438,23 +546,57 @@ class DistributedEngine:
             V = _controlled_on_second(U)
             ctrl, tgt = qb, qa
         if V is not None and ctrl >= k:               # global control: conditional 1q gate
-            if self._rank_bit(ctrl):
-                if tgt < k:
+            if tgt < k:
+                if self._rank_bit(ctrl):
                     self._queue_local(([tgt], V))
-                else:
+            elif _is_diagonal(V):
+                if self._rank_bit(ctrl):
                     self.apply_nonlocal([tgt], V)
+            else:
+                # the target has to come local on EVERY rank (the move is collective); the gate keeps its
+                # global control and is applied by the ranks whose control bit is 1
+                (v,) = self._bring_local([tgt], exclude=())
+                if self._rank_bit(ctrl):
+                    self._queue_local(([v], V))
             return
-        if a_glob and b_glob:                         # dense, both global: group of four ranks
-            self._quad(qa, qb, U)
-            return
-        if a_glob:                                    # qa = partner bit (MSB), qb local
-            self._exchange_full(self._partner(qa))
-            names = ("state", "buf1") if self._rank_bit(qa) == 0 else ("buf1", "state")
-            self.backend.apply_2q_pair_qb_local(names, qb, U)
-        else:                                         # qa local, qb = partner bit (LSB)
-            self._exchange_full(self._partner(qb))
-            names = ("state", "buf1") if self._rank_bit(qb) == 0 else ("buf1", "state")
-            self.backend.apply_2q_pair_qa_local(names, qa, U)
+        # dense: every global qubit of the gate trades places with a local one, then the gate is local
+        moved = self._bring_local([q for q in (qa, qb) if q >= k], exclude=[q for q in (qa, qb) if q < k])
+        it = iter(moved)
+        self._queue_local(([next(it) if qa >= k else qa, next(it) if qb >= k else qb], U))
+
+    def _bring_local(self, glob, exclude) -> list[int]:
+        """Swap-and-stay: the global actual bits `glob` trade places with local bits that are not needed
+        for the longest time; returns the local bits that now hold them.  Half a shard crosses one link for
+        one bit (3/4 over three links for two) and nothing is sent back: `_dyn` records the move."""
+        victims = self._pick_victims(len(glob), set(exclude))
+        self._trace_kind = "swap-and-stay"
+        self.relayout([[v, g] for v, g in zip(victims, glob)])
+        self._trace_kind = "relayout"
+        self._passes += 2
+        # an UNPLANNED move: the contents of the swapped actual positions have traded places, the plans
+        # do not know (a planned re-layout moves planned and actual positions alike: no update there)
+        swap = {}
+        for v, g in zip(victims, glob):
+            swap[v], swap[g] = g, v
+        self._dyn = [swap.get(a, a) for a in self._dyn]
+        return victims
+
+    def _pick_victims(self, count: int, exclude: set) -> list[int]:
+        """Local actual bits whose next use in the running execution is farthest away (never: best)."""
+        if self.k - len(exclude) < count:
+            raise ValueError("not enough local qubits to bring a global gate local")
+        planned_of = {a: p for p, a in enumerate(self._dyn)}
+        next_use = {}
+        want = {planned_of[b] for b in range(self.k) if b not in exclude}
+        for dist, qs in enumerate(self._flat[self._flat_pos + 1:]):
+            for q in qs:
+                if q in want and q not in next_use:
+                    next_use[q] = dist
+            if len(next_use) == len(want):
+                break
+        cands = [b for b in range(self.k) if b not in exclude]
+        cands.sort(key=lambda b: (-next_use.get(planned_of[b], 1 << 60), -b))
+        return cands[:count]
 
     def _scale(self, f) -> None:
         if self.k > 0:
@@ -466,30 +608,6 @@ class DistributedEngine:
         t = self.backend.tensor("state")
         z = complex(t[0].item(), t[1].item()) * complex(f)
         t[0], t[1] = z.real, z.imag
-
-    def _exchange_full(self, peer: int) -> None:
-        """Partner's whole shard into buf1 (apply_*_pair needs both chunks)."""
-        self._flush_local()
-        self._exchange([(peer, self.backend.tensor("state"), self.backend.tensor("buf1"))])
-
-    def _quad(self, qa: int, qb: int, U) -> None:
-        self._flush_local()
-        ba, bb = self._rank_bit(qa), self._rank_bit(qb)
-        me = 2 * ba + bb
-        names = [None] * 4
-        transfers = []
-        free = ["buf1", "buf2", "buf3"]
-        for idx in range(4):
-            if idx == me:
-                names[idx] = "state"
-                continue
-            peer = self.rank
-            peer = (peer & ~(1 << (qa - self.k))) | ((idx >> 1) << (qa - self.k))
-            peer = (peer & ~(1 << (qb - self.k))) | ((idx & 1) << (qb - self.k))
-            names[idx] = free.pop(0)
-            transfers.append((peer, self.backend.tensor("state"), self.backend.tensor(names[idx])))
-        self._exchange(transfers)
-        self.backend.apply_2q_quad(names, U)
 
     # ---- synchronisation / measurement ------------------------------------------------------------
     def barrier(self) -> None:
@@ -517,6 +635,44 @@ class DistributedEngine:
         self._flush_local()
         local = self.backend.closed_form_error(kind, self.n, self.rank << self.k, self.l2p)
         return self.max_over_ranks(local)
+
+    # ---- BASELINE configs 4 and 5 on this engine (bench.py at N > 1, tools/run_config.py) ----------------
+    def _timed_circuit(self, cd: dict):
+        self.init_zero_state()
+        self.reset_comm_stats()
+        plan = self.plan(cd)
+        self.barrier()
+        import time
+        t0 = time.perf_counter()
+        self.execute(plan)
+        self.barrier()
+        dt = self.max_over_ranks(time.perf_counter() - t0)
+        return dt, len(plan.executions[0])
+
+    def run_baseline_configs(self, gen) -> dict:
+        """Config 5: n-qubit GHZ and GHZ+QFT, EVERY amplitude against the closed forms of SURVEY 8c on the
+        devices (max-abs-error over all shards, staged layout included).  Config 4: the seeded Clifford+T
+        circuit (depth 60) with and without staging: gate-applications/s, bytes over xGMI, exchange time."""
+        n = self.n
+        out = {"config5": [], "config4": None}
+        for kind, cd in (("ghz", gen.generate_ghz_circuit(n)), ("ghz_qft", gen.generate_ghz_qft(n))):
+            dt, steps = self._timed_circuit(cd)
+            err = self.closed_form_error(kind)
+            out["config5"].append({"circuit": kind, "n_qubits": n, "n_gpus": self.world, "gates": len(cd["gates"]),
+                                   "seconds": round(dt, 4), "gate_apps_per_s": round(len(cd["gates"]) / dt, 1),
+                                   "steps": steps, "max_abs_err_vs_closed_form": err, "pass_1e-10": bool(err < 1e-10),
+                                   "norm2": self.norm2(), "xgmi": self.comm_stats()})
+        cd = gen.random_clifford_t_circuit(n, depth=60)
+        rec = {"n_qubits": n, "n_gpus": self.world, "gates": len(cd["gates"]), "local_qubits": self.k}
+        saved = self.staging
+        for label, staging in (("staged", True), ("unstaged", False)):
+            self.staging = staging
+            dt, steps = self._timed_circuit(cd)
+            rec[label] = {"seconds": round(dt, 4), "gate_apps_per_s": round(len(cd["gates"]) / dt, 1), "steps": steps,
+                          "hbm_passes": self.last_passes, "norm2": self.norm2(), "xgmi": self.comm_stats()}
+        self.staging = saved
+        out["config4"] = rec
+        return out
 
     def comm_stats(self) -> dict:
         ms = None

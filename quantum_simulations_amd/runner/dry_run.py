@@ -1,0 +1,100 @@
+"""Dry run of the multi-GPU communication schedule (bench.py --gpus N --dry-run, CPU tests).
+
+Every rank runs the REAL `DistributedEngine` -- planning, staging, swap-and-stay moves, pipelined
+re-layout pieces -- at the full problem size (30 local qubits, n = 32 / 33) over a `DryBackend` that
+holds no shard memory and does no arithmetic; each transfer the engine would post is recorded instead
+(peer, bytes sent, bytes expected, kind).  The ranks then exchange their records over gloo and rank 0
+checks what a first run on real RCCL / xGMI would otherwise have to discover:
+
+  * symmetry: the i-th transfer rank a posts towards rank b has the size rank b expects from a in ITS
+    i-th transfer with a (a mismatch is a hang or a truncated receive on RCCL);
+  * every send / receive slice lies inside its buffer (checked when the slice is taken);
+  * every rank posts the same number of transfer groups in the same order of kinds;
+  * bytes per rank match the closed form of each move: a re-layout of m qubits ships (1 - 2^-m) of a shard.
+Rank 0 prints one JSON line per workload; the return value is the process exit code.
+"""
+from __future__ import annotations
+
+import json
+
+from quantum_simulations_amd import circuits as gen
+from quantum_simulations_amd.runner.distributed import DistributedEngine, DryBackend
+
+
+def workloads(n: int) -> list:
+    return [("bench: random 1q+CX depth 40, 2 executions", gen.random_1q_cx_circuit(n, depth=40), True, 2),
+            ("config 4: Clifford+T depth 60, staged", gen.random_clifford_t_circuit(n, depth=60), True, 1),
+            ("config 4: Clifford+T depth 60, unstaged (swap-and-stay)", gen.random_clifford_t_circuit(n, depth=60), False, 1),
+            ("config 5: GHZ", gen.generate_ghz_circuit(n), True, 1),
+            ("config 5: GHZ+QFT", gen.generate_ghz_qft(n), True, 1)]
+
+
+def check(traces: list, world: int, k: int) -> list[str]:
+    """traces[r] = [(kind, peer, sent_bytes, recv_bytes), ...] of rank r -> list of problems."""
+    problems = []
+    for a in range(world):
+        for b in range(a + 1, world):
+            ab = [(kind, s, r) for kind, peer, s, r in traces[a] if peer == b]
+            ba = [(kind, s, r) for kind, peer, s, r in traces[b] if peer == a]
+            if len(ab) != len(ba):
+                problems.append(f"ranks {a} and {b} post {len(ab)} vs {len(ba)} transfers with each other")
+                continue
+            for i, ((ka, sa, ra), (kb, sb, rb)) in enumerate(zip(ab, ba)):
+                if sa != rb or sb != ra or ka != kb:
+                    problems.append(f"transfer {i} between ranks {a} and {b}: {ka} sends {sa} / expects {ra}, "
+                                    f"{kb} sends {sb} / expects {rb}")
+    shard = 16 << k
+    for r, tr in enumerate(traces):
+        if any(s <= 0 or s > shard for _, _, s, _ in tr):
+            problems.append(f"rank {r}: a transfer is empty or larger than a shard")
+    if len({len(tr) for tr in traces}) != 1:
+        problems.append(f"ranks post different numbers of transfers: {[len(tr) for tr in traces]}")
+    return problems
+
+
+def run_world(world: int, rank: int, k: int, emit=print) -> int:
+    import torch.distributed as dist
+    p = world.bit_length() - 1
+    n = k + p
+    failed = 0
+    eng = None
+    for title, cd, staging, repeats in workloads(n):
+        eng = DistributedEngine(n, world, rank, backend=DryBackend(k), staging=staging)
+        eng.init_zero_state()
+        plan = eng.plan(cd, repeats=repeats)
+        for _ in range(repeats):
+            eng.execute(plan)
+        traces = [None] * world
+        dist.all_gather_object(traces, eng.trace)
+        stats = [None] * world
+        dist.all_gather_object(stats, {"bytes": eng.xgmi_bytes_sent, "exchanges": eng.exchanges,
+                                       "local_batches": eng.backend.local_passes, "layout": eng.l2p})
+        if rank == 0:
+            problems = check(traces, world, k)
+            failed += bool(problems)
+            kinds = {}
+            for kind, _, s, _ in traces[0]:
+                kinds.setdefault(kind, [0, 0])
+                kinds[kind][0] += 1
+                kinds[kind][1] += s
+            emit(json.dumps({
+                "dry_run": title, "n_qubits": n, "n_gpus": world, "local_qubits": k, "gates": len(cd["gates"]),
+                "executions": repeats, "ok": not problems, "problems": problems[:8],
+                "per_rank": [{"rank": r, "transfers": len(traces[r]), "bytes_sent": stats[r]["bytes"],
+                              "exchanges": stats[r]["exchanges"], "local_batches": stats[r]["local_batches"]}
+                             for r in range(world)],
+                "rank0_by_kind": {kd: {"transfers": c, "bytes": b} for kd, (c, b) in kinds.items()},
+                "rank0_schedule": [{"kind": kind, "peer": peer, "bytes": s} for kind, peer, s, _ in traces[0][:64]],
+                "final_layout_rank0": stats[0]["layout"]}))
+    flag = [failed]
+    dist.broadcast_object_list(flag, src=0)
+    if eng is not None:
+        eng.close()
+    return 1 if flag[0] else 0
+
+
+def main(world: int, rank: int, k: int) -> int:
+    if world < 2:
+        print(json.dumps({"error": "--dry-run needs --gpus N > 1 under torch.distributed.run (gloo, CPU only)"}))
+        return 2
+    return run_world(world, rank, k)

@@ -41,18 +41,6 @@ class CpuShardBackend:
     def apply_ops(self, ops) -> None:
         orc.apply_ops(self._c("state"), ops)
 
-    def apply_1q_pair(self, names, U) -> None:
-        orc.apply_1q_pair(self._c(names[0]), self._c(names[1]), U)
-
-    def apply_2q_pair_qa_local(self, names, qa, U) -> None:
-        orc.apply_2q_pair_qa_local(self._c(names[0]), self._c(names[1]), qa, U)
-
-    def apply_2q_pair_qb_local(self, names, qb, U) -> None:
-        orc.apply_2q_pair_qb_local(self._c(names[0]), self._c(names[1]), qb, U)
-
-    def apply_2q_quad(self, names, U) -> None:
-        orc.apply_2q_quad(*(self._c(n) for n in names), U)
-
     def _slab_index(self, bits, pattern: int) -> np.ndarray:
         idx = np.arange(1 << self.k, dtype=np.int64)
         keep = np.ones(idx.shape, dtype=bool)

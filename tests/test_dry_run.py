@@ -1,0 +1,71 @@
+"""The multi-GPU communication schedule at FULL problem size without shard memory (`bench.py --gpus N
+--dry-run`): world 4 (n = 32, config 4) and world 8 (n = 33, config 5) over gloo on the CPU.  Every rank runs
+the real DistributedEngine over DryBackend; rank 0 checks send / receive symmetry between every pair of
+ranks, slice bounds and byte counts (quantum_simulations_amd/runner/dry_run.py)."""
+import json
+import os
+import sys
+import traceback
+from pathlib import Path
+
+import pytest
+import torch.multiprocessing as mp
+
+from tests.test_distributed_gloo import _free_port
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _worker(rank, world, port, k, lines, errors):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        sys.path.insert(0, str(ROOT))
+        from quantum_simulations_amd.runner import dry_run
+        rc = dry_run.run_world(world, rank, k, emit=lines.put)
+        assert rc == 0, "the dry run reported a schedule problem"
+    except Exception:
+        errors.put((rank, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_schedule_is_symmetric_at_full_size(world):
+    ctx = mp.get_context("spawn")
+    lines, errors = ctx.SimpleQueue(), ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 30, lines, errors)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    msgs = []
+    while not errors.empty():
+        msgs.append(errors.get())
+    assert not msgs and all(p.exitcode == 0 for p in procs), "\n".join(f"[rank {r}] {m}" for r, m in msgs)
+    docs = []
+    while not lines.empty():
+        docs.append(json.loads(lines.get()))
+    assert len(docs) == 5 and all(d["ok"] and d["n_qubits"] == 30 + world.bit_length() - 1 for d in docs)
+    shard = 16 << 30
+    by_title = {d["dry_run"].split(":")[0] + ":" + d["dry_run"].split(":")[1][:14]: d for d in docs}
+    for d in docs:
+        for kind, agg in d["rank0_by_kind"].items():
+            assert kind in ("relayout", "swap-and-stay")
+            assert 0 < agg["bytes"] <= agg["transfers"] * shard
+        sent = {r["bytes_sent"] for r in d["per_rank"]}
+        assert len(sent) == 1, "every rank ships the same number of bytes"        # (the schedule is symmetric)
+    # GHZ needs exactly one re-layout of all global qubits: (1 - 2^-p) of a shard per rank
+    ghz = next(d for d in docs if d["dry_run"] == "config 5: GHZ")
+    p = world.bit_length() - 1
+    assert ghz["per_rank"][0]["bytes_sent"] == shard - (shard >> p) and ghz["per_rank"][0]["exchanges"] == 1
+    del by_title
+
+
+def test_dry_check_catches_asymmetry():
+    from quantum_simulations_amd.runner.dry_run import check
+    good = [[("relayout", 1, 64, 64)], [("relayout", 0, 64, 64)]]
+    assert check(good, 2, 3) == []
+    bad = [[("relayout", 1, 64, 64)], [("relayout", 0, 32, 64)]]
+    assert check(bad, 2, 3)
+    missing = [[("relayout", 1, 64, 64)], []]
+    assert check(missing, 2, 3)

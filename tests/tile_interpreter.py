@@ -18,8 +18,10 @@ from quantum_simulations_amd.kernel.device import pack_ops
 IMAGE_BYTES = 4096
 STREAM_OFF = 32                    # byte offset of the first record (csrc/tile_kernel.h)
 OPC = dict(DENSE1=1, SWAP1=10, ANTI1=19, PHASE=28, DENSE2=36, REAL1=45, YLIKE1=54, PHASE_NEG=63,
-           PHASE_I=71, PHASE_NI=79, DIAGR=87, PRED_OUTER=91, PRED_LANE=92, GROUP=93, GROUP_FIRST=94, END=95)
-_FAMILIES = ("DENSE1", "SWAP1", "ANTI1", "PHASE", "DENSE2", "REAL1", "YLIKE1", "PHASE_NEG", "PHASE_I", "PHASE_NI", "DIAGR")
+           PHASE_I=71, PHASE_NI=79, DIAGR=87, PRED_OUTER=91, PRED_LANE=92, GROUP=93, GROUP_FIRST=94, END=95,
+           HAD1=96, SCALE=105)
+_FAMILIES = ("DENSE1", "SWAP1", "ANTI1", "PHASE", "DENSE2", "REAL1", "YLIKE1", "PHASE_NEG", "PHASE_I", "PHASE_NI", "DIAGR",
+             "HAD1", "SCALE")
 _IMAGE = np.dtype([("amp", "<u8"), ("nrec", "<i4"), ("T", "<i4"), ("h", "u1", (12,)), ("ntiles", "<u4"),
                    ("stream", "u1", (IMAGE_BYTES - STREAM_OFF,))])
 assert _IMAGE.itemsize == IMAGE_BYTES
@@ -148,7 +150,10 @@ def run_pass(psi: np.ndarray, img) -> int:
         cond = abs_mask(blk) | outer
         fam = max(OPC[f] for f in _FAMILIES if OPC[f] <= op)
         var = op - fam
-        if fam in (OPC["DENSE1"], OPC["SWAP1"], OPC["ANTI1"], OPC["REAL1"], OPC["YLIKE1"]):
+        if fam == OPC["SCALE"]:
+            assert var == 0 and not cond and size == 32
+            psi *= float(dbl(0, 1)[0])
+        elif fam in (OPC["DENSE1"], OPC["SWAP1"], OPC["ANTI1"], OPC["REAL1"], OPC["YLIKE1"], OPC["HAD1"]):
             assert 0 <= var < 9
             if var < 3:
                 J, ctrl = var, None
@@ -161,6 +166,9 @@ def run_pass(psi: np.ndarray, img) -> int:
             elif fam == OPC["YLIKE1"]:
                 U = np.array([[0, -1j], [1j, 0]])
                 assert size == 16
+            elif fam == OPC["HAD1"]:        # unscaled: the pass's SCALE record carries the factors
+                U = np.array([[1, 1], [1, -1]], dtype=complex)
+                assert size == 16 and var < 3 and not cond
             elif fam == OPC["ANTI1"]:
                 m = dbl(0, 4)
                 U = np.array([[0, _c(m[0:2])], [_c(m[2:4]), 0]])
