@@ -62,6 +62,20 @@ def build_steps(cd: dict, k: int, use_fusion: bool, use_staging: bool, staging_m
     return steps, None
 
 
+def _plan_fingerprint(steps, k: int, use_fusion: bool, use_staging: bool, staging_method: str) -> dict:
+    """What `done_steps` of a checkpoint refers to: the step list depends on the planner flags, so a
+    resumed run must have planned the same steps (qubit lists of every step, hashed)."""
+    import hashlib
+    h = hashlib.sha256()
+    for st in steps:
+        for part in ("local_ops", "nonlocal_ops"):
+            h.update(repr([list(map(int, qs)) for qs, _ in st[part]]).encode())
+            h.update(b"|")
+    return {"k": k, "use_fusion": bool(use_fusion), "use_staging": bool(use_staging),
+            "staging_method": staging_method if use_staging else None, "n_steps": len(steps),
+            "steps_sha256": h.hexdigest()}
+
+
 def run(circuit_dict: dict, work_dir: str | Path | None = None, chunk_size: int = 1 << 20,
         kernel: str = "hip", use_wal: bool = True, use_fencing: bool = False,
         use_fusion: bool = False, use_staging: bool = False,
@@ -92,6 +106,20 @@ def run(circuit_dict: dict, work_dir: str | Path | None = None, chunk_size: int 
         from quantum_simulations_amd.wal import WAL
         log = WAL(work / "wal.json", circuit_dict=cd)   # raises on a different circuit
         first_step = min(log.done_steps, len(steps))
+        fingerprint = _plan_fingerprint(steps, k, use_fusion, use_staging, staging_method)
+        plan_path = work / "plan.json"
+        if first_step > 0:
+            # done_steps indexes THIS step list only if the checkpoint was planned with the same flags
+            try:
+                saved = json.loads(plan_path.read_text())
+            except (OSError, ValueError):
+                saved = None
+            if saved != fingerprint:
+                raise ValueError(f"checkpoint in {work} was written under a different plan (chunk_size / use_fusion / "
+                                 f"use_staging / staging_method): saved {saved}, now {fingerprint}; refusing to resume")
+        else:
+            work.mkdir(parents=True, exist_ok=True)
+            plan_path.write_text(json.dumps(fingerprint))
     if first_step > 0:
         state = load_to_device(work / f"state_{log.committed_buf}", device)
         if state.k != n:
@@ -100,13 +128,16 @@ def run(circuit_dict: dict, work_dir: str | Path | None = None, chunk_size: int 
         state = DeviceChunk.zero_state(n, device)  # |0..0>: chunk 0, element 0 = 1 (block_store.py:35-65)
     n_chunks = N // chunk_size
     chunks = [state.view(c * chunk_size, k) for c in range(n_chunks)] if n_chunks > 1 else [state]
+    stats = {"steps": len(steps), "resumed_from_step": first_step, "hbm_passes": 0, "relayouts": 0,
+             "nonlocal_gate_groups": 0, "checkpoints": 0}
     for idx in range(first_step, len(steps)):
         step = steps[idx]
-        _apply_step(state, chunks, step["local_ops"], step["nonlocal_ops"], k)
+        _apply_step(state, chunks, step["local_ops"], step["nonlocal_ops"], k, stats)
         if log is not None and ((idx + 1) % checkpoint_every == 0 or idx + 1 == len(steps)):
             other = "b" if log.committed_buf == "a" else "a"     # never overwrite the committed buffer
             write_state(work / f"state_{other}", state, chunk_size, dtype=checkpoint_dtype)
             log.commit_step(idx, other)
+            stats["checkpoints"] += 1
         if _stop_after_step is not None and idx == _stop_after_step:
             for c in (chunks if n_chunks > 1 else []):
                 c.close()
@@ -119,25 +150,34 @@ def run(circuit_dict: dict, work_dir: str | Path | None = None, chunk_size: int 
             json.dump(log_to_phys, f)
     buf = HbmStateBuffer(state, chunks if n_chunks > 1 else [], n, chunk_size, work)
     buf.log_to_phys = log_to_phys
+    buf.stats = stats          # what actually ran: steps, HBM round trips, re-layouts (fusion_stats-style introspection)
     return buf
 
 
-def _apply_step(state: DeviceChunk, chunks: list[DeviceChunk], local_ops, nonlocal_ops, k: int) -> None:
+def _apply_step(state: DeviceChunk, chunks: list[DeviceChunk], local_ops, nonlocal_ops, k: int,
+                stats: dict | None = None) -> None:
     """One step.  Local ops use bits < k only, so "every chunk gets the same local pass"
     (_process_local_chunk, single_node.py:208-216) is one launch per op over the whole
     allocation; each chunk still sees local ops before its non-local ones (:253-262)."""
+    stats = stats if stats is not None else {"hbm_passes": 0, "relayouts": 0, "nonlocal_gate_groups": 0}
     if local_ops:
-        state.apply_ops(local_ops)
+        stats["hbm_passes"] += state.apply_ops(local_ops)
     if nonlocal_ops:
         pairs = _relayout_pairs(nonlocal_ops, k)
+        if pairs is not None:
+            stats["relayouts"] += 1
+        else:
+            stats["nonlocal_gate_groups"] += 1
         if pairs is not None and len(pairs) <= 3 and min(lo for lo, _ in pairs) < _SUBLINE_BITS:
             # a local bit inside a 128-B line: the slab exchange would touch 16 B of every line
             # (tools/relayout_probe.py: 0.65 TB/s); on ONE allocation the same permutation is a
             # set of SWAP gates between index bits of the whole state = one fused tile pass
-            state.apply_ops(nonlocal_ops)
+            stats["hbm_passes"] += state.apply_ops(nonlocal_ops)
         elif pairs is not None and len(pairs) <= 3:   # a staging SWAP list: ONE all-to-all re-layout
+            stats["hbm_passes"] += 1
             gpu_nonlocal.swap_global_local(chunks, [hi - k for _, hi in pairs], [lo for lo, _ in pairs])
         else:
+            stats["hbm_passes"] += len(nonlocal_ops)
             _process_nonlocal_groups(chunks, nonlocal_ops, k)
 
 

@@ -7,7 +7,9 @@ docs/storage_spec.md) and, after staging, `<work_dir>/qubit_mapping.json`
 finished run in that format, so the reference's own `collect_state(buf_path, ...)` can read a
 GPU result, and read such a directory back into HBM.  Checkpoints of the GPU runner
 (runner/single_node.run(checkpoint_every=...)) use the same layout with `"dtype": "complex128"`
-so a resumed run loses nothing; the reference's complex64 stays the default for exports.
+so a resumed run of THIS build loses nothing (the reference's `Manifest.validate` accepts complex64
+only: checkpoints it should read must be written with checkpoint_dtype="complex64"); complex64 stays
+the default for exports.
 """
 from __future__ import annotations
 

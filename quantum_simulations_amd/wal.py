@@ -3,9 +3,14 @@
 Interoperates with wenbo_engine/wal/wal.py:25-93: the file holds exactly the three fields
 "circuit_hash", "committed_buf" ("a" | "b") and "done_steps", is replaced atomically, and the
 circuit identity is that module's (wal.py:17-22: sha256 over the validated circuit dict, first 16
-hex digits) -- so either side can resume a run the other one checkpointed.  The GPU runner
-commits every `checkpoint_every` steps instead of every step: the state lives in HBM and a
-checkpoint is a full download (runner/single_node.py).
+hex digits).  Resuming ACROSS the two implementations is limited to what both agree on: unstaged runs
+(`use_staging=False`: this build plans staged circuits with `strict_order=True`, which splits steps the
+reference does not -- w_qft(6) at k = 3 is 9 steps here, 7 there -- so `done_steps` would point at
+different gates) checkpointed as complex64 (`checkpoint_dtype="complex64"`: the reference's
+`Manifest.validate` rejects any other dtype).  This build's own resume additionally checks the planner
+flags through the `plan.json` sidecar (runner/single_node.py).  The GPU runner commits every
+`checkpoint_every` steps instead of every step: the state lives in HBM and a checkpoint is a full
+download.
 """
 from __future__ import annotations
 

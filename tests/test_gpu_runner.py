@@ -255,7 +255,15 @@ def test_checkpoint_resume_after_injected_stop(tmp_path):
         buf = run(cd, work, chunk_size=1 << 7, checkpoint_every=2, **kwargs)
         np.testing.assert_allclose(collect_state(buf, apply_permutation=True, work_dir=work), want,
                                    rtol=0, atol=1e-12)
+        assert buf.stats["resumed_from_step"] == buf.stats["steps"] and buf.stats["hbm_passes"] == 0
         buf.close()
+        # done_steps indexes the step list of ONE plan: other planner flags must not resume it (plan.json)
+        with pytest.raises(ValueError, match="different plan"):
+            run(cd, work, chunk_size=1 << 6, checkpoint_every=2, **kwargs)
+        flipped = dict(kwargs, use_fusion=not kwargs.get("use_fusion", False))
+        if not kwargs.get("use_staging"):
+            with pytest.raises(ValueError, match="different plan"):
+                run(cd, work, chunk_size=1 << 7, checkpoint_every=2, **flipped)
 
 
 def test_checkpoint_every_step_writes_reference_wal(tmp_path):
