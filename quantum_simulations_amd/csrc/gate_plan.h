@@ -41,6 +41,7 @@ struct Tuning {
   int tile_merge_diag = 1;   // merge phase gates that share their predicate (OPC_DIAGR)
   int tile_had = QSIM_TILE_HAD_DEFAULT;          // uncontrolled c [[1,1],[1,-1]] as add/sub butterflies + one scale per pass (OPC_HAD1 / OPC_SCALE)
   int debug_skip_gates = 0;  // probe build only: QSIM_DEBUG_SKIP_GATES=1: tile passes move data but apply nothing (WRONG results)
+  int tile_order = -1;       // probe build only: QSIM_TILE_ORDER=0/1/2 forces the tile order of k_tile
   int debug_stats = 0;       // QSIM_DEBUG_STATS=1: print gates / groups per pass to stderr
   // States up to this size stay in the 256 MiB Infinity Cache between launches when accessed with
   // the default cache policy (tools/mall_probe.hip: 8.5-8.8 TB/s r+w for a 128-256 MiB region vs
@@ -62,6 +63,7 @@ struct Tuning {
     if (const char* e = getenv("QSIM_NT")) force_nt = atoi(e);
     if (const char* e = getenv("QSIM_ITEMS")) items = atoi(e);
     if (const char* e = getenv("QSIM_DEBUG_SKIP_GATES")) debug_skip_gates = atoi(e);
+    if (const char* e = getenv("QSIM_TILE_ORDER")) tile_order = atoi(e);
 #endif
   }
 };

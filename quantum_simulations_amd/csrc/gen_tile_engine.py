@@ -43,6 +43,9 @@ import sys
 # Generation-time variants (A/B builds): QS_GEN_TAILS=1 ends every gate body with the fetch + dispatch
 # of the next record instead of a branch to the shared copy of that sequence.
 TAILS = os.environ.get("QS_GEN_TAILS", "0") == "1"
+# PROBE ONLY (wrong results): QS_GEN_NOBARRIER=1 drops the barrier of register-group changes, to
+# measure what the barriers cost.
+NOBARRIER = os.environ.get("QS_GEN_NOBARRIER", "0") == "1"
 
 # ---- entry numbers (header dword 0 = 4 * entry); the gate families keep the r01 opcode numbers ----
 OPC = dict(NOP=0, DENSE1=1, SWAP1=10, ANTI1=19, PHASE=28, DENSE2=36, REAL1=45, YLIKE1=54,
@@ -449,7 +452,7 @@ def engine(partial: bool) -> list[str]:
         a("s_waitcnt lgkmcnt(0)")
         if partial:
             a("s_mov_b64 exec, -1")
-        a("s_barrier")
+        a("s_nop 0" if NOBARRIER else "s_barrier")
         a.label("group_first_" + bank)
         # record dwords: 2..4 = insert-zero masks (~0 << s_i, ascending), 5..11 = XOR constants of x1..x7
         a(f"v_and_b32 {VT}, {HD(bank, 2)}, {TID}")

@@ -83,8 +83,9 @@ struct TileArgs {
   double2* amp;
   int nrec;                // records in the stream incl. END (host bookkeeping; the device follows the stream)
   int T;                   // tile size of the pass (read by the pass-image consumers; the kernel is a template)
-  uint8_t h[12];           // ascending absolute positions of the tile's high bits
-  uint32_t ntiles;         // 2^(k - T): the resident grid walks the tiles with stride gridDim.x
+  uint8_t h[11];           // ascending absolute positions of the tile's high bits
+  uint8_t order;           // tile order of the launch: 0 consecutive, 1 hashed, 2 bit-reversed (see k_tile)
+  uint32_t ntiles;         // 2^(k - T)
   uint32_t stream[kTileStreamBytes / 4];
 };
 static_assert(sizeof(TileArgs) == kTileArgBytes, "kernel arguments are one 4 KiB block");
@@ -150,7 +151,14 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
     return o;
   };
   const auto karg = __builtin_amdgcn_kernarg_segment_ptr();
+  // Which tile a workgroup takes.  Workgroups are dispatched in blockIdx order, so the tiles in flight at
+  // any moment are those of consecutive block numbers; with consecutive TILES in flight (order 0) the
+  // gate-less pass takes 1.4-2.4 ms depending on which index bits the tile holds (HBM channel pattern,
+  // profiles/r02f_tile_order_probe.txt).  order 1 = multiplicative hash (tiles in flight scattered over the
+  // state), 2 = bit reversal (they differ in the HIGHEST non-tile bits).  ntiles is a power of two.
   unsigned tile = blockIdx.x;                         // (the host launches at most ntiles workgroups)
+  if (a.order == 1) tile = (tile * 0x9E3779B1u) & (a.ntiles - 1);
+  if (a.order == 2) tile = a.ntiles > 1 ? __brev(tile) >> (__clz(a.ntiles) + 1) : 0;
   u64 base = tile_base(tile);
   double2 v[PER];
 #pragma unroll

@@ -85,6 +85,18 @@ static bool classify_op(int nq, const int32_t* q, const double* U, FusedOp* o) {
   return true;
 }
 
+// Tile order of a launch (k_tile).  Gate-less passes depend strongly on it (profiles/r02f_tile_order_probe.txt:
+// 2.38 -> 1.58 ms for tile bits {3,4,5,6,18,19,20,21} with bit-reversed order, 1.90 -> 1.70 ms averaged over ten
+// tile-bit sets with a bits-above-18 rule), but passes that carry their gates do not: per pass the best of the
+// three orders is within 2 % of consecutive tiles on the bench circuit (profiles/r02i_pass_times_by_order.txt),
+// so the product launches consecutive tiles; the other orders stay reachable in the probe build.
+static int tile_order_for(const TileArgs&, int) {
+#ifdef QSIM_PROBES
+  if (tuning().tile_order >= 0) return tuning().tile_order;
+#endif
+  return 0;
+}
+
 template <int T>
 static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t stream, double alg_bytes) {
   if constexpr (T > kTileBitsMax) {
@@ -94,6 +106,7 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   if (ntiles > 0xFFFFFFFFull) return fail(QSIM_ERR_INVALID, "internal: too many tiles");
   TileArgs args = a;
   args.ntiles = (uint32_t)ntiles;
+  args.order = (uint8_t)tile_order_for(a, T);
   // resident grid: what the device holds at once (LDS: 160 KiB / tile bytes, at most 8 workgroups of
   // 4 waves per CU), never more workgroups than tiles
   static int n_cu = 0;

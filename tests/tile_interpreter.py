@@ -22,7 +22,7 @@ OPC = dict(DENSE1=1, SWAP1=10, ANTI1=19, PHASE=28, DENSE2=36, REAL1=45, YLIKE1=5
            HAD1=96, SCALE=105)
 _FAMILIES = ("DENSE1", "SWAP1", "ANTI1", "PHASE", "DENSE2", "REAL1", "YLIKE1", "PHASE_NEG", "PHASE_I", "PHASE_NI", "DIAGR",
              "HAD1", "SCALE")
-_IMAGE = np.dtype([("amp", "<u8"), ("nrec", "<i4"), ("T", "<i4"), ("h", "u1", (12,)), ("ntiles", "<u4"),
+_IMAGE = np.dtype([("amp", "<u8"), ("nrec", "<i4"), ("T", "<i4"), ("h", "u1", (11,)), ("order", "u1"), ("ntiles", "<u4"),
                    ("stream", "u1", (IMAGE_BYTES - STREAM_OFF,))])
 assert _IMAGE.itemsize == IMAGE_BYTES
 
