@@ -62,10 +62,16 @@ __global__ void k_scale(double2* p, u64 n, double s) {
 
 // NT: streaming (non-temporal) accesses for copies larger than the Infinity Cache -- the same cache
 // policy the gate kernels use; this copy is also bench.py's same-run device-to-device ceiling.
-template <bool NT>
-__global__ void k_copy(double2* __restrict__ dst, const double2* __restrict__ src, u64 n) {
-  const u64 stride = (u64)gridDim.x * blockDim.x;
-  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) st_amp<NT>(dst + i, ld_amp<NT>(src + i));
+// One-shot grid, ITEMS 16-byte elements per thread, XCD-contiguous block order (the shape of the gate
+// kernels: grid-stride loops are 5-8 % slower, tools/bw_probe.hip).
+template <bool NT, int ITEMS>
+__global__ __launch_bounds__(kBlock) void k_copy(double2* __restrict__ dst, const double2* __restrict__ src, u64 n) {
+  const u64 first = (logical_block<true>() * ITEMS) * kBlock + threadIdx.x;
+  double2 v[ITEMS];
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) if (first + (u64)r * kBlock < n) v[r] = ld_amp<NT>(src + first + (u64)r * kBlock);
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) if (first + (u64)r * kBlock < n) st_amp<NT>(dst + first + (u64)r * kBlock, v[r]);
 }
 
 // dst[j] = src[insert(j, bit, value)]  /  inverse

@@ -209,10 +209,13 @@ int qsim_copy(qsim_chunk* dst, const qsim_chunk* src) {
   if (dst->k != src->k) return fail(QSIM_ERR_INVALID, "qsim_copy: sizes differ");
   if (dst->amp == src->amp) return QSIM_OK;
   HIP_TRY(hipSetDevice(dst->device));
+  constexpr int kItems = 2;
+  u64 blocks = (amps(dst) + (u64)kBlock * kItems - 1) / ((u64)kBlock * kItems);
+  blocks = (blocks + 7) & ~7ull;                     // whole octets: logical_block<true> deals blocks over the 8 XCDs
   if ((sizeof(double2) << dst->k) > tuning().mall_bytes)
-    hipLaunchKernelGGL((k_copy<true>), dim3(stream_grid(amps(dst))), dim3(kBlock), 0, dst->stream, dst->amp, src->amp, amps(dst));
+    hipLaunchKernelGGL((k_copy<true, kItems>), grid_for(blocks), dim3(kBlock), 0, dst->stream, dst->amp, src->amp, amps(dst));
   else
-    hipLaunchKernelGGL((k_copy<false>), dim3(stream_grid(amps(dst))), dim3(kBlock), 0, dst->stream, dst->amp, src->amp, amps(dst));
+    hipLaunchKernelGGL((k_copy<false, kItems>), grid_for(blocks), dim3(kBlock), 0, dst->stream, dst->amp, src->amp, amps(dst));
   HIP_TRY(hipGetLastError());
   return QSIM_OK;
 }

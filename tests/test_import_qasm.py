@@ -1,0 +1,149 @@
+"""OpenQASM 2.0 front-end (circuit/import_qasm.py): exact mappings only, everything else "unsupported gate".
+No reference fixture exists for it (the reference's Python path never reads QASM): parity unpinned; the
+checks here are against explicit matrices on small registers, through the oracle."""
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import dense_oracle as orc
+from quantum_simulations_amd.circuit.import_qasm import qasm_to_dict
+from quantum_simulations_amd.circuit.io import validate_circuit_dict
+
+HDR = 'OPENQASM 2.0;\ninclude "qelib1.inc";\n'
+
+
+def _state(cd, psi0=None):
+    cd = validate_circuit_dict(cd)
+    n = cd["number_of_qubits"]
+    psi = np.zeros(1 << n, dtype=np.complex128) if psi0 is None else psi0.copy()
+    if psi0 is None:
+        psi[0] = 1
+    for g in cd["gates"]:
+        U = orc.gate_matrix(g["gate"], g["params"])
+        (orc.apply_1q if len(g["qubits"]) == 1 else orc.apply_2q)(psi, *g["qubits"], U)
+    return psi
+
+
+def _rand(n, seed):
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    return v / np.linalg.norm(v)
+
+
+def test_bell_and_broadcast_and_registers():
+    cd = qasm_to_dict(HDR + "qreg a[2]; qreg b[1]; creg c[3];\nh a[0]; cx a[0],a[1]; // bell\nx b; barrier a; measure a -> c;")
+    assert cd["number_of_qubits"] == 3
+    assert [(g["gate"], g["qubits"]) for g in cd["gates"]] == [("H", [0]), ("CNOT", [0, 1]), ("X", [2])]
+    psi = _state(cd)
+    want = np.zeros(8, dtype=complex)
+    want[0b100] = want[0b111] = 2 ** -0.5
+    np.testing.assert_allclose(psi, want, atol=1e-15)
+    cd = qasm_to_dict(HDR + "qreg q[3]; h q; cx q[0],q[2];")
+    assert [g["gate"] for g in cd["gates"]] == ["H", "H", "H", "CNOT"]
+
+
+def test_dagger_gates_and_dyadic_phases_are_exact():
+    psi0 = _rand(2, 1)
+    for src, diag in (("sdg q[1];", [1, -1j]), ("tdg q[1];", [1, np.exp(-1j * math.pi / 4)]),
+                      ("u1(pi/8) q[1];", [1, np.exp(1j * math.pi / 8)]),
+                      ("u1(-3*pi/16) q[1];", [1, np.exp(-3j * math.pi / 16)]),
+                      ("p(2*pi) q[1];", [1, 1]), ("u1(pi) q[1];", [1, -1])):
+        got = _state(qasm_to_dict(HDR + "qreg q[2];" + src), psi0)
+        want = psi0.copy()
+        orc.apply_1q(want, 1, np.diag(diag).astype(complex))
+        np.testing.assert_allclose(got, want, atol=1e-14, err_msg=src)
+    got = _state(qasm_to_dict(HDR + "qreg q[2]; cu1(pi/4) q[0],q[1]; cp(-pi/2) q[1],q[0];"), psi0)
+    want = psi0.copy()
+    want[3] *= np.exp(1j * math.pi / 4) * np.exp(-1j * math.pi / 2)
+    np.testing.assert_allclose(got, want, atol=1e-14)
+
+
+def test_toffoli_and_fredkin_decompositions():
+    for src, perm in (("ccx q[0],q[1],q[2];", {0b011: 0b111, 0b111: 0b011}),
+                      ("cswap q[2],q[0],q[1];", {0b101: 0b110, 0b110: 0b101})):
+        cd = qasm_to_dict(HDR + "qreg q[3];" + src)
+        psi0 = _rand(3, 7)
+        got = _state(cd, psi0)
+        want = psi0.copy()
+        for a, b in perm.items():
+            want[b] = psi0[a]
+        np.testing.assert_allclose(got, want, atol=1e-14, err_msg=src)
+
+
+def test_user_gate_definitions_expand():
+    src = HDR + """qreg q[3];
+gate majority a,b,c { cx c,b; cx c,a; ccx a,b,c; }
+gate rot(t) a { ry(t/2) a; ry(t/2) a; }
+majority q[0],q[1],q[2];
+rot(pi/3) q[1];"""
+    cd = qasm_to_dict(src)
+    names = [g["gate"] for g in cd["gates"]]
+    assert names[:2] == ["CNOT", "CNOT"] and names[-2:] == ["RY", "RY"] and len(names) == 2 + (15 + 3 * 2) + 2   # each of the 3 tdg is Z S T
+    assert cd["gates"][0]["qubits"] == [2, 1] and cd["gates"][-1]["params"]["theta"] == pytest.approx(math.pi / 6)
+    psi0 = _rand(3, 3)
+    got = _state(cd, psi0)
+    want = psi0.copy()
+    orc.apply_2q(want, 2, 1, orc.gate_matrix("CNOT"))
+    orc.apply_2q(want, 2, 0, orc.gate_matrix("CNOT"))
+    tof = want.copy()
+    tof[0b011], tof[0b111] = want[0b111], want[0b011]
+    orc.apply_1q(tof, 1, orc.gate_matrix("RY", {"theta": math.pi / 3}))
+    np.testing.assert_allclose(got, tof, atol=1e-14)
+
+
+def test_qft_written_with_u1_and_cx_equals_the_fourier_transform():
+    """The QASMBench QFT shape: controlled phases decomposed into u1 + cx + u1 + cx + u1."""
+    n = 4
+    lines = [HDR, f"qreg q[{n}];"]
+    for j in reversed(range(n)):
+        lines.append(f"h q[{j}];")
+        for k in reversed(range(j)):
+            lam = f"pi/{1 << (j - k)}"
+            lines += [f"u1({lam}/2) q[{j}];", f"cx q[{k}],q[{j}];", f"u1(-{lam}/2) q[{j}];", f"cx q[{k}],q[{j}];",
+                      f"u1({lam}/2) q[{k}];"]
+    cd = qasm_to_dict("\n".join(lines))
+    assert {g["gate"] for g in cd["gates"]} <= {"H", "R", "CNOT"}
+    psi0 = _rand(n, 11)
+    got = _state(cd, psi0)
+    N = 1 << n
+    rev = [int(format(i, f"0{n}b")[::-1], 2) for i in range(N)]            # this QFT leaves the output bit-reversed
+    F = np.array([[np.exp(2j * math.pi * x * y / N) for x in range(N)] for y in range(N)]) / math.sqrt(N)
+    want = (F @ psi0)[rev]
+    np.testing.assert_allclose(got, want, atol=1e-13)
+
+
+@pytest.mark.parametrize("src,what", [
+    ("rz(0.3) q[0];", "rz"), ("u3(1,2,3) q[0];", "u3"), ("rx(pi) q[0];", "rx"), ("u1(0.3) q[0];", "u1"),
+    ("reset q[0];", "reset"), ("h q[0]; measure q[0] -> c[0]; x q[0];", "x"), ("crz(pi) q[0],q[1];", "crz"),
+    ("if(c==1) x q[0];", "if")])
+def test_everything_else_is_an_unsupported_gate(src, what):
+    with pytest.raises(ValueError, match="unsupported gate"):
+        qasm_to_dict(HDR + "qreg q[2]; creg c[2];" + src)
+
+
+def test_malformed_input():
+    for src in ("qreg q[2]; h q[5];", "h q[0];", "qreg q[2]; cx q[0],q[0];", "qreg q[2]; cx q[0];"):
+        with pytest.raises(ValueError):
+            qasm_to_dict(HDR + src)
+
+
+def test_qasmbench_inputs_of_the_reference_when_present():
+    """Informational: which of the QASMBench inputs that ship with the reference are expressible.  Reads the
+    reference tree only if it exists (never on the GPU box)."""
+    root = Path("/root/reference/v3_hisvsim_spark/hisvsim_repo/QASMBench/cluster")
+    if not root.exists():
+        pytest.skip("reference tree not present")
+    ok, rejected = [], []
+    for path in sorted(root.glob("*/*.qasm")):
+        if path.stat().st_size > 400_000:
+            continue
+        try:
+            cd = validate_circuit_dict(qasm_to_dict(path.read_text()))
+            ok.append((path.parent.name, cd["number_of_qubits"], len(cd["gates"])))
+        except ValueError as e:
+            assert "unsupported gate" in str(e), (path, e)
+            rejected.append(path.parent.name)
+    assert len(ok) >= 25, (ok, rejected)
+    assert {"qft_n20", "adder_n28", "bv_n30", "grover_n30", "cat_state_n30"} <= {name for name, _, _ in ok}
