@@ -95,29 +95,22 @@ static_assert(offsetof(TileArgs, stream) == kTileStreamOff, "record offsets are 
 // conflicts are not what limits the gate phase).  Linear over GF(2): the engine relies on it.
 __host__ __device__ __forceinline__ unsigned lds_slot(unsigned t) { return t ^ ((t >> 4) & 15u); }
 
-// Build-time variants (A/B with tools/ab_libs.sh): resident grid that walks the tiles, and whether the
-// next tile's global loads are issued before the finished tile is stored (needs 64 data registers at once).
-#ifndef QSIM_TILE_PERSIST
-#define QSIM_TILE_PERSIST 0
-#endif
-#ifndef QSIM_TILE_PREFETCH
-#define QSIM_TILE_PREFETCH 0
-#endif
-#ifndef QSIM_TILE_WAVES
-#define QSIM_TILE_WAVES 5
-#endif
 // min waves per SIMD asked of the register allocator: what the LDS footprint admits, capped
 constexpr int tile_waves(int T) {
-  return (160 * 1024) / ((1 << T) * 16) > QSIM_TILE_WAVES ? QSIM_TILE_WAVES : (160 * 1024) / ((1 << T) * 16);
+  return (160 * 1024) / ((1 << T) * 16) > 5 ? 5 : (160 * 1024) / ((1 << T) * 16);
 }
 
-// One workgroup per tile.  Measured alternatives (profiles/r02b_ab_persist.txt, same device and session):
-// a resident grid walking the tiles with stride gridDim.x is 29 % SLOWER (2.47 vs 1.92 ms per pass: its
-// workgroups run their load / compute / store phases in lockstep, so HBM idles while they compute; freshly
-// dispatched workgroups stagger by themselves), and so is that grid with the next tile's loads issued
-// before the finished tile is stored (2.36 ms, 106 VGPRs -> 4 workgroups per CU).  Both stay selectable
-// at build time (QSIM_TILE_PERSIST / QSIM_TILE_PREFETCH) for A/B runs.
-template <int T, bool NT>
+// One workgroup per tile.  Measured alternatives (profiles/r02b_ab_persist.txt, r02d_ab_tiles_per_wg.txt, same
+// device and session): a resident grid walking the tiles with stride gridDim.x is 29 % SLOWER (2.47 vs 1.92 ms
+// per pass: its workgroups run their load / compute / store phases in lockstep, so HBM idles while they
+// compute; freshly dispatched workgroups stagger by themselves); 2 or 4 tiles per workgroup 2-4 % slower; the
+// next tile's loads issued before the finished tile is stored (106 VGPRs -> 4 workgroups per CU) no gain.
+//
+// WIDE = false: the thread part of an element's byte offset fits 32 bits (its highest index bit is below 28,
+// always true for states of up to 31 qubits): every access is `global_* v, voffset, s[base]` with a scalar
+// 64-bit base per element row -- no 64-bit vector arithmetic (the r01 form spent ~35 quarter-rate
+// v_lshl_add_u64 / v_lshlrev_b64 per wave and pass on addresses).
+template <int T, bool NT, bool WIDE>
 __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const TileArgs a) {
   constexpr int N = 1 << T;
   constexpr int LOW = kTileLow;
@@ -129,85 +122,71 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
   static_assert(N >= BLOCK && NBLK <= BLOCK, "one register block per thread, at least one element per thread");
   __shared__ double2 lds[N];                          // the only LDS object: the engine addresses it from 0
   const int tid = threadIdx.x;
-  // global index of a tile's element 0: the tile number enumerates the non-tile bits
-  auto tile_base = [&](unsigned tile_no) -> u64 {
-    u64 base = (u64)tile_no << LOW;
+  // Which tile a workgroup takes: 0 = consecutive tiles in flight, 1 = hashed, 2 = bit-reversed (probe
+  // build only, see tile_order_for).  ntiles is a power of two.
+  unsigned tile = blockIdx.x;
+  if (a.order == 1) tile = (tile * 0x9E3779B1u) & (a.ntiles - 1);
+  if (a.order == 2) tile = a.ntiles > 1 ? __brev(tile) >> (__clz(a.ntiles) + 1) : 0;
+  int hs[NH];                                         // the tile's high bits, pinned to scalar registers
 #pragma unroll
-    for (int j = 0; j < NH; ++j) {
-      const int p = a.h[j];
-      base = ((base >> p) << (p + 1)) | (base & ((1ull << p) - 1));
-    }
-    return base;
-  };
+  for (int j = 0; j < NH; ++j) hs[j] = __builtin_amdgcn_readfirstlane((int)a.h[j]);
+  // global index of the tile's element 0: the tile number enumerates the non-tile bits
+  u64 base = (u64)tile << LOW;
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    const int p = hs[j];
+    base = ((base >> p) << (p + 1)) | (base & ((1ull << p) - 1));
+  }
   // element t = tid + BLOCK * j -> row = (tid >> LOW) | (j << (TB - LOW)): the thread part of the
   // offset is computed once, the j part is wave-uniform (scalar registers)
-  u64 off_tid = tid & ((1 << LOW) - 1);
+  using off_t = typename std::conditional<WIDE, u64, unsigned>::type;   // !WIDE: every h[i] used here is < 28
+  off_t off_tid = tid & ((1 << LOW) - 1);
 #pragma unroll
-  for (int i = 0; i < TB - LOW && i < NH; ++i) off_tid |= (u64)((tid >> (LOW + i)) & 1) << a.h[i];
+  for (int i = 0; i < TB - LOW && i < NH; ++i) off_tid |= (off_t)((tid >> (LOW + i)) & 1) << hs[i];
   auto off_j = [&](int j) -> u64 {
     u64 o = 0;
 #pragma unroll
-    for (int i = TB - LOW; i < NH; ++i) o |= (u64)((j >> (i - (TB - LOW))) & 1) << a.h[i];
+    for (int i = TB - LOW; i < NH; ++i) o |= (u64)((j >> (i - (TB - LOW))) & 1) << hs[i];
     return o;
   };
-  const auto karg = __builtin_amdgcn_kernarg_segment_ptr();
-  // Which tile a workgroup takes.  Workgroups are dispatched in blockIdx order, so the tiles in flight at
-  // any moment are those of consecutive block numbers; with consecutive TILES in flight (order 0) the
-  // gate-less pass takes 1.4-2.4 ms depending on which index bits the tile holds (HBM channel pattern,
-  // profiles/r02f_tile_order_probe.txt).  order 1 = multiplicative hash (tiles in flight scattered over the
-  // state), 2 = bit reversal (they differ in the HIGHEST non-tile bits).  ntiles is a power of two.
-  unsigned tile = blockIdx.x;                         // (the host launches at most ntiles workgroups)
-  if (a.order == 1) tile = (tile * 0x9E3779B1u) & (a.ntiles - 1);
-  if (a.order == 2) tile = a.ntiles > 1 ? __brev(tile) >> (__clz(a.ntiles) + 1) : 0;
-  u64 base = tile_base(tile);
-  double2 v[PER];
+  auto element = [&](int j) -> double2* {
+    if constexpr (WIDE) {
+      return a.amp + base + off_tid + off_j(j);
+    } else {
+      char* row = reinterpret_cast<char*>(a.amp + base + off_j(j));            // wave-uniform
+      return reinterpret_cast<double2*>(row + (off_tid << 4));                 // + 32-bit thread offset
+    }
+  };
+  {
+    double2 v[PER];
 #pragma unroll
-  for (int j = 0; j < PER; ++j) v[j] = ld_amp<NT>(a.amp + base + off_tid + off_j(j));
-  for (;;) {
+    for (int j = 0; j < PER; ++j) v[j] = ld_amp<NT>(element(j));
 #pragma unroll
     for (int j = 0; j < PER; ++j) lds[lds_slot(tid + BLOCK * j)] = v[j];
-    __syncthreads();
-    // ---- gate engine: interprets a.stream on the tile in LDS; returns after its last barrier ----
-    {
-      const unsigned baseh = __builtin_amdgcn_readfirstlane((unsigned)(base >> LOW));
-      if constexpr (NBLK == BLOCK) {
-        asm volatile(QS_ENGINE_ASM_FULL
-                     :
-                     : [tid] "v"(tid), [karg] "s"(karg), [baseh] "s"(baseh), [first] "i"(kTileStreamOff)
-                     : QS_ENGINE_CLOBBERS);
-      } else {
-        asm volatile(QS_ENGINE_ASM_PARTIAL
-                     :
-                     : [tid] "v"(tid), [karg] "s"(karg), [baseh] "s"(baseh), [first] "i"(kTileStreamOff), [nblk] "s"(NBLK)
-                     : QS_ENGINE_CLOBBERS);
-      }
+  }
+  __syncthreads();
+  // ---- gate engine: interprets a.stream on the tile in LDS; returns after its last barrier ----
+  {
+    const auto karg = __builtin_amdgcn_kernarg_segment_ptr();
+    const unsigned baseh = __builtin_amdgcn_readfirstlane((unsigned)(base >> LOW));
+    if constexpr (NBLK == BLOCK) {
+      asm volatile(QS_ENGINE_ASM_FULL
+                   :
+                   : [tid] "v"(tid), [karg] "s"(karg), [baseh] "s"(baseh), [first] "i"(kTileStreamOff)
+                   : QS_ENGINE_CLOBBERS);
+    } else {
+      asm volatile(QS_ENGINE_ASM_PARTIAL
+                   :
+                   : [tid] "v"(tid), [karg] "s"(karg), [baseh] "s"(baseh), [first] "i"(kTileStreamOff), [nblk] "s"(NBLK)
+                   : QS_ENGINE_CLOBBERS);
     }
+  }
+  {
     double2 w[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) w[j] = lds[lds_slot(tid + BLOCK * j)];
-    const u64 done_base = base;
-#if QSIM_TILE_PERSIST
-    tile += gridDim.x;
-    const bool more = tile < a.ntiles;                // uniform: every wave of the grid leaves the loop
-#else
-    const bool more = false;
-#endif
-#if QSIM_TILE_PREFETCH
-    if (more) {
-      base = tile_base(tile);
 #pragma unroll
-      for (int j = 0; j < PER; ++j) v[j] = ld_amp<NT>(a.amp + base + off_tid + off_j(j));
-    }
-#endif
-#pragma unroll
-    for (int j = 0; j < PER; ++j) st_amp<NT>(a.amp + done_base + off_tid + off_j(j), w[j]);
-    if (!more) break;
-#if !QSIM_TILE_PREFETCH
-    base = tile_base(tile);
-#pragma unroll
-    for (int j = 0; j < PER; ++j) v[j] = ld_amp<NT>(a.amp + base + off_tid + off_j(j));
-#endif
-    __syncthreads();                                  // every wave has read its part of the finished tile
+    for (int j = 0; j < PER; ++j) st_amp<NT>(element(j), w[j]);
   }
 }
 

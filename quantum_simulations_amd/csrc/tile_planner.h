@@ -107,24 +107,17 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   TileArgs args = a;
   args.ntiles = (uint32_t)ntiles;
   args.order = (uint8_t)tile_order_for(a, T);
-  // resident grid: what the device holds at once (LDS: 160 KiB / tile bytes, at most 8 workgroups of
-  // 4 waves per CU), never more workgroups than tiles
-  static int n_cu = 0;
-  if (!n_cu) {
-    hipDeviceProp_t prop;
-    n_cu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
-  const int per_cu = std::min(8, (160 * 1024) / ((1 << T) * 16));
-#if QSIM_TILE_PERSIST && defined(QSIM_TILE_PER_WG)
-  const unsigned grid = (unsigned)std::max<u64>(1, ntiles / QSIM_TILE_PER_WG);     // a few tiles per workgroup
-#else
-  const unsigned grid = QSIM_TILE_PERSIST ? (unsigned)std::min<u64>(ntiles, (u64)n_cu * std::min(per_cu, QSIM_TILE_WAVES)) : (unsigned)ntiles;
-#endif
+  const unsigned grid = (unsigned)ntiles;
+  // thread part of an element offset: tile high bits h[0 .. min(5, NH)): 32-bit addressing when all are < 28
+  bool wide = false;
+  for (int i = 0; i < kTileThreadBits - kTileLow && i < T - kTileLow; ++i) wide = wide || a.h[i] >= 28;
   ProfileScope prof(6, alg_bytes, stream, 32.0 * (double)amps(c));
   bool nt = c->span_bytes > tuning().mall_bytes;       // cache policy by state size (gate_plan.h)
   if (tuning().force_nt >= 0) nt = tuning().force_nt != 0;
-  if (nt) hipLaunchKernelGGL((k_tile<T, true>), dim3(grid), dim3(kTileThreads), 0, stream, args);
-  else hipLaunchKernelGGL((k_tile<T, false>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+  if (nt && wide) hipLaunchKernelGGL((k_tile<T, true, true>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+  else if (nt) hipLaunchKernelGGL((k_tile<T, true, false>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+  else if (wide) hipLaunchKernelGGL((k_tile<T, false, true>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+  else hipLaunchKernelGGL((k_tile<T, false, false>), dim3(grid), dim3(kTileThreads), 0, stream, args);
   prof.done(stream);
   HIP_TRY(hipGetLastError());
   return QSIM_OK;
