@@ -46,6 +46,9 @@ TAILS = os.environ.get("QS_GEN_TAILS", "0") == "1"
 # PROBE ONLY (wrong results): QS_GEN_NOBARRIER=1 drops the barrier of register-group changes, to
 # measure what the barriers cost.
 NOBARRIER = os.environ.get("QS_GEN_NOBARRIER", "0") == "1"
+# PROBE ONLY: extra instructions per record in the fetch + dispatch sequence, e.g. QS_GEN_PAD="s_nop 0*4"
+PAD = os.environ.get("QS_GEN_PAD", "")
+
 
 # ---- entry numbers (header dword 0 = 4 * entry); the gate families keep the r01 opcode numbers ----
 OPC = dict(NOP=0, DENSE1=1, SWAP1=10, ANTI1=19, PHASE=28, DENSE2=36, REAL1=45, YLIKE1=54,
@@ -373,6 +376,10 @@ def top_sequence(a, bank):
     """Record held in `bank` has arrived (after the wait): fetch the next one into the other bank, dispatch."""
     nb = BANK[other(bank)]
     a("s_mov_b64 exec, -1")
+    if PAD:
+        ins, _, cnt = PAD.partition("*")
+        for _ in range(int(cnt or 1)):
+            a(ins)
     a("s_waitcnt lgkmcnt(0)")
     a(f"s_load_dwordx16 s[{nb}:{nb + 15}], s[26:27], {HD(bank, 1)}")
     dispatch(a, bank, HD(bank, 0))

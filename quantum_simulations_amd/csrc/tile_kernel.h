@@ -104,7 +104,8 @@ constexpr int tile_waves(int T) {
 // device and session): a resident grid walking the tiles with stride gridDim.x is 29 % SLOWER (2.47 vs 1.92 ms
 // per pass: its workgroups run their load / compute / store phases in lockstep, so HBM idles while they
 // compute; freshly dispatched workgroups stagger by themselves); 2 or 4 tiles per workgroup 2-4 % slower; the
-// next tile's loads issued before the finished tile is stored (106 VGPRs -> 4 workgroups per CU) no gain.
+// next tile's loads issued before the finished tile is stored (106 VGPRs -> 4 workgroups per CU) no gain;
+// s_setprio 3 around the load and store phases (and 2 around register-group changes): 0.0 % (r02o_ab_prio.txt).
 //
 // WIDE = false: the thread part of an element's byte offset fits 32 bits (its highest index bit is below 28,
 // always true for states of up to 31 qubits): every access is `global_* v, voffset, s[base]` with a scalar
