@@ -7,10 +7,13 @@ quantum_simulations_amd/csrc`) loading raises `QsimLibraryMissing`.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 LIB_NAME = "libqsim_hip.so"
-LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
+# QSIM_LIBRARY: another build of the same ABI (tools/ load the probe build libqsim_hip_probes.so this way;
+# bench.py refuses to run with any QSIM_* variable set, so a timed number always comes from libqsim_hip.so)
+LIB_PATH = Path(os.environ.get("QSIM_LIBRARY") or (Path(__file__).resolve().parent / LIB_NAME))
 
 QSIM_OK = 0
 QSIM_ERR_INVALID = -1

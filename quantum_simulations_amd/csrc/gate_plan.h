@@ -101,7 +101,7 @@ static hipEvent_t prof_event() {
     return e;
   }
   hipEvent_t e = nullptr;
-  (void)hipEventCreate(&e);
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;   // the launch goes untimed (ProfileScope drops it)
   return e;
 }
 
@@ -116,6 +116,12 @@ struct ProfileScope {  // RAII around one launch
     rec.hbm_bytes = hbm_bytes < 0 ? bytes : hbm_bytes;
     rec.e0 = prof_event();
     rec.e1 = prof_event();
+    if (!rec.e0 || !rec.e1) {               // no event available: keep what we got for reuse, time nothing
+      if (rec.e0) g_prof.pool.push_back(rec.e0);
+      if (rec.e1) g_prof.pool.push_back(rec.e1);
+      on = false;
+      return;
+    }
     (void)hipEventRecord(rec.e0, stream);
   }
   void done(hipStream_t stream) {

@@ -122,6 +122,11 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
   constexpr int NBLK = N >> kGroupBits;               // register blocks per tile (<= BLOCK)
   static_assert(N >= BLOCK && NBLK <= BLOCK, "one register block per thread, at least one element per thread");
   __shared__ double2 lds[N];                          // the only LDS object: the engine addresses it from 0
+#ifdef QSIM_PROBES
+  // in-kernel stamps (probe build): entry / tile loaded / engine done / stores issued, per sampled workgroup
+  unsigned long long* const stamps = *reinterpret_cast<unsigned long long* const*>(&a.stream[(kTileArgBytes - 8 - kTileStreamOff) / 4]);
+  const unsigned long long t_entry = __builtin_readcyclecounter();
+#endif
   const int tid = threadIdx.x;
   // Which tile a workgroup takes: 0 = consecutive tiles in flight, 1 = hashed, 2 = bit-reversed (probe
   // build only, see tile_order_for).  ntiles is a power of two.
@@ -166,6 +171,9 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
     for (int j = 0; j < PER; ++j) lds[lds_slot(tid + BLOCK * j)] = v[j];
   }
   __syncthreads();
+#ifdef QSIM_PROBES
+  const unsigned long long t_loaded = __builtin_readcyclecounter();
+#endif
   // ---- gate engine: interprets a.stream on the tile in LDS; returns after its last barrier ----
   {
     const auto karg = __builtin_amdgcn_kernarg_segment_ptr();
@@ -182,6 +190,9 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
                    : QS_ENGINE_CLOBBERS);
     }
   }
+#ifdef QSIM_PROBES
+  const unsigned long long t_engine = __builtin_readcyclecounter();
+#endif
   {
     double2 w[PER];
 #pragma unroll
@@ -189,6 +200,12 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
 #pragma unroll
     for (int j = 0; j < PER; ++j) st_amp<NT>(element(j), w[j]);
   }
+#ifdef QSIM_PROBES
+  if (stamps && tid == 0 && (blockIdx.x & 63) == 0) {
+    unsigned long long* o = stamps + 4 * (blockIdx.x >> 6);
+    o[0] = t_entry; o[1] = t_loaded; o[2] = t_engine; o[3] = __builtin_readcyclecounter();
+  }
+#endif
 }
 
 // ---- host: logical descriptors of a pass and their serialisation -----------------------------------

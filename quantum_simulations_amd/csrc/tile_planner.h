@@ -107,6 +107,16 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   TileArgs args = a;
   args.ntiles = (uint32_t)ntiles;
   args.order = (uint8_t)tile_order_for(a, T);
+#ifdef QSIM_PROBES
+  {   // in-kernel stamps: QSIM_DEBUG_STAMPS=<file> dumps entry / loaded / engine / stored cycle stamps of every 64th workgroup
+    static unsigned long long* dbuf = nullptr;
+    static const char* path = getenv("QSIM_DEBUG_STAMPS");
+    if (path && !dbuf) (void)hipMalloc((void**)&dbuf, sizeof(unsigned long long) * 4 * ((1u << 22)));
+    unsigned long long* p = path ? dbuf : nullptr;
+    std::memcpy(reinterpret_cast<unsigned char*>(&args) + kTileArgBytes - 8, &p, 8);
+    if (p) (void)hipMemsetAsync(p, 0, sizeof(unsigned long long) * 4 * (ntiles / 64 + 1), stream);
+  }
+#endif
   const unsigned grid = (unsigned)ntiles;
   // thread part of an element offset: tile high bits h[0 .. min(5, NH)): 32-bit addressing when all are < 28
   bool wide = false;
@@ -120,6 +130,21 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   else hipLaunchKernelGGL((k_tile<T, false, false>), dim3(grid), dim3(kTileThreads), 0, stream, args);
   prof.done(stream);
   HIP_TRY(hipGetLastError());
+#ifdef QSIM_PROBES
+  if (const char* path = getenv("QSIM_DEBUG_STAMPS")) {
+    unsigned long long* p = nullptr;
+    std::memcpy(&p, reinterpret_cast<unsigned char*>(&args) + kTileArgBytes - 8, 8);
+    std::vector<unsigned long long> host(4 * (ntiles / 64 + 1));
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(host.data(), p, host.size() * 8, hipMemcpyDeviceToHost);
+    if (FILE* f = std::fopen(path, "a")) {
+      std::fprintf(f, "# pass nrec %d ntiles %llu\n", a.nrec, (u64)ntiles);
+      for (size_t i = 0; i + 3 < host.size(); i += 4)
+        if (host[i]) std::fprintf(f, "%llu %llu %llu %llu\n", host[i], host[i + 1], host[i + 2], host[i + 3]);
+      std::fclose(f);
+    }
+  }
+#endif
   return QSIM_OK;
   }
 }

@@ -124,3 +124,69 @@ def test_world4_gloo():
 
 def test_world8_gloo():
     _run(8, 7, [(True, "belady"), (True, "heuristic"), (False, "heuristic")])
+
+
+# ---- swap-and-stay: a dense gate on a global qubit moves HALF a shard, once ------------------------------
+def _sas_worker(rank, world, port, errors):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        sys.path.insert(0, str(ROOT))
+        from oracle import dense_oracle as orc
+        from quantum_simulations_amd.circuit.io import validate_circuit_dict
+        from quantum_simulations_amd.runner.distributed import DistributedEngine
+        from tests.cpu_shard_backend import CpuShardBackend
+        n, p = 8, world.bit_length() - 1
+        k = n - p
+        shard_bytes = 16 << k
+        eng = DistributedEngine(n, world, rank, backend=CpuShardBackend(k), staging=False,
+                                relayout_pieces=1, min_piece_qubits=1)
+        # H on the top (global) qubit, a local gate, then gates that find the moved qubits again
+        cd = {"number_of_qubits": n, "gates": [
+            {"qubits": [n - 1], "gate": "H"}, {"qubits": [0], "gate": "H"}, {"qubits": [n - 1], "gate": "RY", "params": {"theta": 0.3}},
+            {"qubits": [n - 1, 0], "gate": "CNOT"}, {"qubits": [k - 1], "gate": "H"}, {"qubits": [n - 1], "gate": "T"}]}
+        eng.init_zero_state()
+        eng.reset_comm_stats()
+        eng.execute(eng.plan(cd))
+        stats = eng.comm_stats()
+        # the first H brings qubit n-1 local (half a shard, one exchange); RY / CNOT / T then find it local; the
+        # qubit that was evicted is needed once (H on planned bit k-1 or wherever the victim went) at most
+        assert 1 <= stats["exchanges"] <= 2, stats
+        assert stats["bytes_sent_per_rank"] == stats["exchanges"] * shard_bytes // 2, stats
+        assert eng.l2p != list(range(n))                       # the layout really changed
+        err = float(np.max(np.abs(eng.state_vector() - orc.simulate(validate_circuit_dict(cd)))))
+        assert err < 1e-13, err
+        eng.backend.close()
+        # a plan made for another layout is refused instead of silently applying gates to the wrong bits
+        # (ADVICE r01): staged engine, plan two executions, run one, re-initialise, run the second
+        from quantum_simulations_amd import circuits as gen
+        eng = DistributedEngine(n, world, rank, backend=CpuShardBackend(k), staging=True, min_piece_qubits=1)
+        eng.init_zero_state()
+        plan2 = eng.plan(gen.generate_ghz_qft(n), repeats=2)
+        eng.execute(plan2)
+        assert plan2.start_mappings[1] != list(range(n)), "the staged layout should differ after one execution"
+        eng.init_zero_state()
+        try:
+            eng.execute(plan2)
+            raise AssertionError("a stale plan was accepted")
+        except RuntimeError as e:
+            assert "re-plan" in str(e)
+        eng.close()
+    except Exception:
+        errors.put((rank, traceback.format_exc()))
+        raise
+
+
+def test_swap_and_stay_bytes_and_stale_plans():
+    world = 2
+    ctx = mp.get_context("spawn")
+    errors = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sas_worker, args=(r, world, port, errors)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    msgs = []
+    while not errors.empty():
+        msgs.append(errors.get())
+    assert not msgs and all(p.exitcode == 0 for p in procs), "\n".join(f"[rank {r}] {m}" for r, m in msgs)

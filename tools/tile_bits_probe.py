@@ -8,6 +8,10 @@ import os
 import subprocess
 import sys
 
+# probe build of the library (make -C quantum_simulations_amd/csrc probes): the product build reads no probe knobs
+_PROBES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "quantum_simulations_amd", "libqsim_hip_probes.so")
+os.environ.setdefault("QSIM_LIBRARY", os.path.abspath(_PROBES))
+
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 28
 child = r'''
 import sys
