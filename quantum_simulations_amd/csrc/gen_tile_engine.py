@@ -48,6 +48,7 @@ TAILS = os.environ.get("QS_GEN_TAILS", "0") == "1"
 NOBARRIER = os.environ.get("QS_GEN_NOBARRIER", "0") == "1"
 # PROBE ONLY: extra instructions per record in the fetch + dispatch sequence, e.g. QS_GEN_PAD="s_nop 0*4"
 PAD = os.environ.get("QS_GEN_PAD", "")
+PAD_AFTER = os.environ.get("QS_GEN_PAD_AFTER", "")      # ... the same after the wait for the record
 
 
 # ---- entry numbers (header dword 0 = 4 * entry); the gate families keep the r01 opcode numbers ----
@@ -381,6 +382,10 @@ def top_sequence(a, bank):
         for _ in range(int(cnt or 1)):
             a(ins)
     a("s_waitcnt lgkmcnt(0)")
+    if PAD_AFTER:
+        ins, _, cnt = PAD_AFTER.partition("*")
+        for _ in range(int(cnt or 1)):
+            a(ins)
     a(f"s_load_dwordx16 s[{nb}:{nb + 15}], s[26:27], {HD(bank, 1)}")
     dispatch(a, bank, HD(bank, 0))
 
