@@ -8,7 +8,7 @@ rotation, so only what maps EXACTLY is accepted:
 
     h x y z s t ry cx cz cy swap id                 one gate each
     sdg = Z S, tdg = Z S T                          (diagonal, exact)
-    u1 / p (lambda), cu1 / cp (lambda)              when lambda = 2 pi m / 2^K, K <= 30: a product of R(k) / CR(k)
+    u1 / p (lambda), cu1 / cp (lambda)              when lambda = 2 pi m / 2^K, K <= 48: a product of R(k) / CR(k)
     ccx, cswap                                      the standard 15-gate Clifford+T decomposition
     user `gate` definitions                         expanded in place
     barrier, measure (terminal), creg               dropped
@@ -29,7 +29,7 @@ _SIMPLE = {"h": "H", "x": "X", "y": "Y", "z": "Z", "s": "S", "t": "T", "cx": "CN
 _ARITY = {"h": 1, "x": 1, "y": 1, "z": 1, "s": 1, "t": 1, "sdg": 1, "tdg": 1, "id": 1, "ry": 1, "u1": 1, "p": 1,
           "cx": 2, "cnot": 2, "cz": 2, "cy": 2, "swap": 2, "cu1": 2, "cp": 2, "ccx": 3, "cswap": 3}
 _NPARAMS = {"ry": 1, "u1": 1, "p": 1, "cu1": 1, "cp": 1}
-_MAX_K = 30
+_MAX_K = 48
 
 
 def _unsupported(name: str, why: str = "") -> ValueError:
@@ -112,14 +112,19 @@ def _eval_expr(text: str, env: dict) -> float:
 
 
 def _phase_powers(name: str, lam: float) -> list[int]:
-    """lambda = 2 pi m / 2^K exactly (to 1e-12 of a turn) -> the k's with diag(1, e^{i lambda}) = prod R(k)."""
+    """lambda = 2 pi m / 2^K exactly (to the precision a double angle carries) -> the k's with
+    diag(1, e^{i lambda}) = prod R(k): the smallest K <= 48 for which lambda / 2 pi * 2^K is an integer."""
     turns = (lam / (2.0 * math.pi)) % 1.0
-    scaled = turns * (1 << _MAX_K)
-    m = round(scaled)
-    if abs(scaled - m) > 1e-12 * (1 << _MAX_K) * 4:
-        raise _unsupported(name, f"angle {lam!r} is not a multiple of 2 pi / 2^{_MAX_K}")
-    m %= 1 << _MAX_K
-    return [k for k in range(1, _MAX_K + 1) if (m >> (_MAX_K - k)) & 1]
+    for K in range(0, _MAX_K + 1):
+        x = turns * (1 << K)
+        slack = 4e-15 * x                      # what the rounding of lam / (2 pi) can have moved x by
+        if slack > 1e-3:
+            break
+        m = round(x)
+        if abs(x - m) <= max(1e-9, slack):
+            m %= 1 << K
+            return [k for k in range(1, K + 1) if (m >> (K - k)) & 1]
+    raise _unsupported(name, f"angle {lam!r} is not a multiple of 2 pi / 2^k (k <= {_MAX_K})")
 
 
 def _emit_builtin(name: str, params: list[float], q: list[int], out: list) -> None:
