@@ -62,4 +62,25 @@ while time.time() - t0 < budget:
             worst = max(worst, err)
             assert err < 1e-10, (n, cs, kw, err)
     cases += 1
+# large states, every gate kind, against the C oracle: many waves per SIMD, full tiles, 32-bit and (n >= 29)
+# 64-bit thread offsets are NOT reached here -- the 33-qubit tests of test_gpu_kernels cover those
+from oracle import c_oracle  # noqa: E402
+big_cases = 0
+t1 = time.time()
+while time.time() - t1 < budget * 0.5:
+    n = int(rng.integers(21, 26))
+    seed = int(rng.integers(1 << 30))
+    ops = _random_ops(n, int(rng.integers(60, 200)), seed)
+    psi0 = _rand_state(n, seed)
+    want = psi0.copy()
+    for qs, U in ops:
+        (c_oracle.apply_1q if len(qs) == 1 else c_oracle.apply_2q)(want, *qs, np.ascontiguousarray(U, dtype=np.complex128))
+    dev = DeviceChunk.from_numpy(psi0)
+    dev.apply_ops(ops, fused=True)
+    err = float(np.max(np.abs(dev.download() - want)))
+    dev.close()
+    worst = max(worst, err)
+    assert err < 1e-10, ("big", n, seed, err)
+    big_cases += 1
+print(f"stress ok: {big_cases} large cases (21-25 qubits, fused) in {time.time() - t1:.0f} s")
 print(f"stress ok: {cases} random cases in {time.time() - t0:.0f} s, worst |diff| = {worst:.2e}")
