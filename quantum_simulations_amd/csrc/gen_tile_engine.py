@@ -27,7 +27,7 @@ block (tile_kernel.h, `TileArgs::stream`):
 Fixed registers (listed as clobbers of the asm statement):
   v[4:35]   x0..x7 (complex128 each: .x = v[4+4j:5+4j], .y = v[6+4j:7+4j])
   v[36:43]  LDS byte addresses of x0..x7      v44 tb (thread's tile index with the group bits 0)
-  v45 scratch   v46 tid   v[48:63] eight f64 temporaries
+  v45 scratch   v[46:61] eight f64 temporaries   (the thread id is read from the operand's register)
   s[16:17] scratch pair  s18 scratch  s19 base >> 3 (outer predicate)
   s[20:21] / s[22:23] branch-table base of bank A / B   s[24:25] jump target
   s[26:27] kernel-argument pointer   s[28:29] mask of live lanes (tiles smaller than 8 x blockDim)
@@ -71,14 +71,14 @@ def XD(j, c):        # dword c (0..3) of amplitude register j
 
 
 def T(k):
-    return f"v[{48 + 2 * k}:{49 + 2 * k}]"
+    return f"v[{46 + 2 * k}:{47 + 2 * k}]"
 
 
 def A(j):
     return f"v{36 + j}"
 
 
-TB, VT, TID = "v44", "v45", "v46"
+TB, VT, TID = "v44", "v45", "%[tid]"     # (the thread id stays in the compiler's register)
 
 
 def M(bank, k):      # k-th in-record double of the bank's record
@@ -403,7 +403,6 @@ def engine(partial: bool) -> list[str]:
     block (operand %[nblk]); they alone touch LDS."""
     a = Asm()
     cases = gate_cases()
-    a(f"v_mov_b32 {TID}, %[tid]")
     a("s_mov_b64 s[26:27], %[karg]")
     a("s_mov_b32 s19, %[baseh]")
     if partial:
@@ -504,7 +503,7 @@ def engine(partial: bool) -> list[str]:
 
 
 def clobbers() -> str:
-    regs = [f"v{i}" for i in range(4, 64)] + [f"s{i}" for i in range(16, 30)] + [f"s{i}" for i in range(36, 84)] + ["vcc", "scc", "memory"]
+    regs = [f"v{i}" for i in range(4, 62)] + [f"s{i}" for i in range(16, 30)] + [f"s{i}" for i in range(36, 84)] + ["vcc", "scc", "memory"]
     return ", ".join(f'"{r}"' for r in regs)
 
 

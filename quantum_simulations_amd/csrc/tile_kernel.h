@@ -96,23 +96,27 @@ static_assert(offsetof(TileArgs, stream) == kTileStreamOff, "record offsets are 
 __host__ __device__ __forceinline__ unsigned lds_slot(unsigned t) { return t ^ ((t >> 4) & 15u); }
 
 // min waves per SIMD asked of the register allocator: what the LDS footprint admits, capped
-constexpr int tile_waves(int T) {
+constexpr int tile_waves(int T, int tiles_per_wg = 1) {   // (with a prefetched tile in flight the kernel needs 95 VGPRs: still 5)
   return (160 * 1024) / ((1 << T) * 16) > 5 ? 5 : (160 * 1024) / ((1 << T) * 16);
 }
 
-// One workgroup per tile.  Measured alternatives (profiles/r02b_ab_persist.txt, r02d_ab_tiles_per_wg.txt, same
-// device and session): a resident grid walking the tiles with stride gridDim.x is 29 % SLOWER (2.47 vs 1.92 ms
-// per pass: its workgroups run their load / compute / store phases in lockstep, so HBM idles while they
-// compute; freshly dispatched workgroups stagger by themselves); 2 or 4 tiles per workgroup 2-4 % slower; the
-// next tile's loads issued before the finished tile is stored (106 VGPRs -> 4 workgroups per CU) no gain;
+// TPW tiles per workgroup (1 or 2): with 2, the second tile's global loads are issued BEFORE the gate engine
+// runs on the first and land while it works (the engine issues no vector-memory operation), which hides one
+// of the two load latencies of the pair: -3.9 % per pass (profiles/r02r_ab_prefetch_before_engine.txt) at 95
+// VGPRs (the engine's registers were packed into v4..v61 and the C++ part keeps no address VGPRs for that).
+// Other shapes measured on the same device and session (profiles/r02b_ab_persist.txt, r02d_ab_tiles_per_wg.txt):
+// a resident grid walking all tiles is 29 % SLOWER (2.47 vs 1.92 ms per pass: its workgroups run their load /
+// compute / store phases in lockstep, so HBM idles while they compute; freshly dispatched workgroups stagger
+// by themselves); 4 / 8 tiles per workgroup give the gain of 2 back; 2 tiles WITHOUT the early loads: +2 %; the
+// next tile's loads issued only before the finished tile is stored: no gain;
 // s_setprio 3 around the load and store phases (and 2 around register-group changes): 0.0 % (r02o_ab_prio.txt).
 //
 // WIDE = false: the thread part of an element's byte offset fits 32 bits (its highest index bit is below 28,
 // always true for states of up to 31 qubits): every access is `global_* v, voffset, s[base]` with a scalar
 // 64-bit base per element row -- no 64-bit vector arithmetic (the r01 form spent ~35 quarter-rate
 // v_lshl_add_u64 / v_lshlrev_b64 per wave and pass on addresses).
-template <int T, bool NT, bool WIDE>
-__global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const TileArgs a) {
+template <int T, bool NT, bool WIDE, int TPW>
+__global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const TileArgs a) {
   constexpr int N = 1 << T;
   constexpr int LOW = kTileLow;
   constexpr int NH = T - LOW;                         // tile high bits
@@ -126,26 +130,15 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
   // in-kernel stamps (probe build): entry / tile loaded / engine done / stores issued, per sampled workgroup
   unsigned long long* const stamps = *reinterpret_cast<unsigned long long* const*>(&a.stream[(kTileArgBytes - 8 - kTileStreamOff) / 4]);
   const unsigned long long t_entry = __builtin_readcyclecounter();
+  unsigned long long t_loaded = 0, t_engine = 0;
 #endif
   const int tid = threadIdx.x;
-  // Which tile a workgroup takes: 0 = consecutive tiles in flight, 1 = hashed, 2 = bit-reversed (probe
-  // build only, see tile_order_for).  ntiles is a power of two.
-  unsigned tile = blockIdx.x;
-  if (a.order == 1) tile = (tile * 0x9E3779B1u) & (a.ntiles - 1);
-  if (a.order == 2) tile = a.ntiles > 1 ? __brev(tile) >> (__clz(a.ntiles) + 1) : 0;
   int hs[NH];                                         // the tile's high bits, pinned to scalar registers
 #pragma unroll
   for (int j = 0; j < NH; ++j) hs[j] = __builtin_amdgcn_readfirstlane((int)a.h[j]);
-  // global index of the tile's element 0: the tile number enumerates the non-tile bits
-  u64 base = (u64)tile << LOW;
-#pragma unroll
-  for (int j = 0; j < NH; ++j) {
-    const int p = hs[j];
-    base = ((base >> p) << (p + 1)) | (base & ((1ull << p) - 1));
-  }
+  using off_t = typename std::conditional<WIDE, u64, unsigned>::type;   // !WIDE: every h[i] used here is < 28
   // element t = tid + BLOCK * j -> row = (tid >> LOW) | (j << (TB - LOW)): the thread part of the
   // offset is computed once, the j part is wave-uniform (scalar registers)
-  using off_t = typename std::conditional<WIDE, u64, unsigned>::type;   // !WIDE: every h[i] used here is < 28
   off_t off_tid = tid & ((1 << LOW) - 1);
 #pragma unroll
   for (int i = 0; i < TB - LOW && i < NH; ++i) off_tid |= (off_t)((tid >> (LOW + i)) & 1) << hs[i];
@@ -155,50 +148,81 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T)) void k_tile(const Tile
     for (int i = TB - LOW; i < NH; ++i) o |= (u64)((j >> (i - (TB - LOW))) & 1) << hs[i];
     return o;
   };
-  auto element = [&](int j) -> double2* {
+  // Which tile a workgroup takes: TPW consecutive tiles per workgroup; order 0 = consecutive tiles in flight,
+  // 1 = hashed, 2 = bit-reversed (probe build only, see tile_order_for).  ntiles is a power of two.
+  auto tile_base = [&](unsigned i) -> u64 {
+    unsigned tile = blockIdx.x * TPW + i;
+    if (a.order == 1) tile = (tile * 0x9E3779B1u) & (a.ntiles - 1);
+    if (a.order == 2) tile = a.ntiles > 1 ? __brev(tile) >> (__clz(a.ntiles) + 1) : 0;
+    u64 base = (u64)tile << LOW;                      // the tile number enumerates the non-tile bits
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int p = hs[j];
+      base = ((base >> p) << (p + 1)) | (base & ((1ull << p) - 1));
+    }
+    return base;
+  };
+  auto element = [&](u64 base, int j) -> double2* {
     if constexpr (WIDE) {
       return a.amp + base + off_tid + off_j(j);
     } else {
-      char* row = reinterpret_cast<char*>(a.amp + base + off_j(j));            // wave-uniform
-      return reinterpret_cast<double2*>(row + (off_tid << 4));                 // + 32-bit thread offset
+      // wave-uniform row base pinned to scalar registers + 32-bit thread offset: `global_* v, voff, s[row]`,
+      // no 64-bit vector address is formed (or kept alive across the engine)
+      const u64 r = reinterpret_cast<u64>(a.amp + base + off_j(j));
+      const u64 row = ((u64)__builtin_amdgcn_readfirstlane((unsigned)(r >> 32)) << 32) |
+                      (unsigned)__builtin_amdgcn_readfirstlane((unsigned)r);
+      return reinterpret_cast<double2*>(reinterpret_cast<char*>(row) + (off_tid << 4));
     }
   };
-  {
-    double2 v[PER];
+  const unsigned slot0 = lds_slot(tid);               // element tid + BLOCK * j sits BLOCK * j slots further (the swizzle uses bits 4-7 only)
+  static_assert(BLOCK >= 256, "lds_slot(tid + BLOCK * j) = lds_slot(tid) + BLOCK * j needs BLOCK to be a multiple of 256");
+  u64 base = tile_base(0);
+  double2 v[PER];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) v[j] = ld_amp<NT>(element(j));
+  for (int j = 0; j < PER; ++j) v[j] = ld_amp<NT>(element(base, j));
+#pragma unroll 1
+  for (int it = 0; it < TPW; ++it) {                  // (rolled: one copy of the 92 KiB engine)
 #pragma unroll
-    for (int j = 0; j < PER; ++j) lds[lds_slot(tid + BLOCK * j)] = v[j];
-  }
-  __syncthreads();
-#ifdef QSIM_PROBES
-  const unsigned long long t_loaded = __builtin_readcyclecounter();
-#endif
-  // ---- gate engine: interprets a.stream on the tile in LDS; returns after its last barrier ----
-  {
-    const auto karg = __builtin_amdgcn_kernarg_segment_ptr();
-    const unsigned baseh = __builtin_amdgcn_readfirstlane((unsigned)(base >> LOW));
-    if constexpr (NBLK == BLOCK) {
-      asm volatile(QS_ENGINE_ASM_FULL
-                   :
-                   : [tid] "v"(tid), [karg] "s"(karg), [baseh] "s"(baseh), [first] "i"(kTileStreamOff)
-                   : QS_ENGINE_CLOBBERS);
-    } else {
-      asm volatile(QS_ENGINE_ASM_PARTIAL
-                   :
-                   : [tid] "v"(tid), [karg] "s"(karg), [baseh] "s"(baseh), [first] "i"(kTileStreamOff), [nblk] "s"(NBLK)
-                   : QS_ENGINE_CLOBBERS);
+    for (int j = 0; j < PER; ++j) lds[slot0 + BLOCK * j] = v[j];
+    __syncthreads();
+    // TPW > 1: the NEXT tile's loads are issued before the gate engine runs and land while it works (the
+    // engine issues no vector-memory operation and waits for none)
+    const u64 cur = base;
+    if (it + 1 < TPW) {
+      base = tile_base(it + 1);
+#pragma unroll
+      for (int j = 0; j < PER; ++j) v[j] = ld_amp<NT>(element(base, j));
     }
-  }
 #ifdef QSIM_PROBES
-  const unsigned long long t_engine = __builtin_readcyclecounter();
+    if (it == 0) t_loaded = __builtin_readcyclecounter();
 #endif
-  {
-    double2 w[PER];
+    // ---- gate engine: interprets a.stream on the tile in LDS; returns after its last barrier ----
+    {
+      const auto karg = __builtin_amdgcn_kernarg_segment_ptr();
+      const unsigned baseh = __builtin_amdgcn_readfirstlane((unsigned)(cur >> LOW));
+      if constexpr (NBLK == BLOCK) {
+        asm volatile(QS_ENGINE_ASM_FULL
+                     :
+                     : [tid] "v"(tid), [karg] "s"(karg), [baseh] "s"(baseh), [first] "i"(kTileStreamOff)
+                     : QS_ENGINE_CLOBBERS);
+      } else {
+        asm volatile(QS_ENGINE_ASM_PARTIAL
+                     :
+                     : [tid] "v"(tid), [karg] "s"(karg), [baseh] "s"(baseh), [first] "i"(kTileStreamOff), [nblk] "s"(NBLK)
+                     : QS_ENGINE_CLOBBERS);
+      }
+    }
+#ifdef QSIM_PROBES
+    if (it == 0) t_engine = __builtin_readcyclecounter();
+#endif
+    {
+      double2 w[PER];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) w[j] = lds[lds_slot(tid + BLOCK * j)];
+      for (int j = 0; j < PER; ++j) w[j] = lds[slot0 + BLOCK * j];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) st_amp<NT>(element(j), w[j]);
+      for (int j = 0; j < PER; ++j) st_amp<NT>(element(cur, j), w[j]);
+    }
+    if (it + 1 < TPW) __syncthreads();                // every wave has read its part of the finished tile
   }
 #ifdef QSIM_PROBES
   if (stamps && tid == 0 && (blockIdx.x & 63) == 0) {

@@ -117,17 +117,31 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
     if (p) (void)hipMemsetAsync(p, 0, sizeof(unsigned long long) * 4 * (ntiles / 64 + 1), stream);
   }
 #endif
-  const unsigned grid = (unsigned)ntiles;
+#ifndef QSIM_TILES_PER_WG
+#define QSIM_TILES_PER_WG 2
+#endif
   // thread part of an element offset: tile high bits h[0 .. min(5, NH)): 32-bit addressing when all are < 28
   bool wide = false;
   for (int i = 0; i < kTileThreadBits - kTileLow && i < T - kTileLow; ++i) wide = wide || a.h[i] >= 28;
   ProfileScope prof(6, alg_bytes, stream, 32.0 * (double)amps(c));
   bool nt = c->span_bytes > tuning().mall_bytes;       // cache policy by state size (gate_plan.h)
   if (tuning().force_nt >= 0) nt = tuning().force_nt != 0;
-  if (nt && wide) hipLaunchKernelGGL((k_tile<T, true, true>), dim3(grid), dim3(kTileThreads), 0, stream, args);
-  else if (nt) hipLaunchKernelGGL((k_tile<T, true, false>), dim3(grid), dim3(kTileThreads), 0, stream, args);
-  else if (wide) hipLaunchKernelGGL((k_tile<T, false, true>), dim3(grid), dim3(kTileThreads), 0, stream, args);
-  else hipLaunchKernelGGL((k_tile<T, false, false>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+  // Two tiles per workgroup, the second one's loads in flight while the first is computed on
+  // (profiles/r02r_ab_prefetch_before_engine.txt: -3.9 % per pass at 95 VGPRs, still 5 workgroups per CU; 4 or 8
+  // tiles per workgroup lose it again).  Not for the 64-bit-offset form (one VGPR too many: it would spill) and
+  // not for small grids.
+  constexpr int TPW = QSIM_TILES_PER_WG;
+  if (TPW > 1 && !wide && ntiles >= (u64)TPW * 4096) {
+    const unsigned grid = (unsigned)(ntiles / TPW);
+    if (nt) hipLaunchKernelGGL((k_tile<T, true, false, TPW>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+    else hipLaunchKernelGGL((k_tile<T, false, false, TPW>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+  } else {
+    const unsigned grid = (unsigned)ntiles;
+    if (nt && wide) hipLaunchKernelGGL((k_tile<T, true, true, 1>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+    else if (nt) hipLaunchKernelGGL((k_tile<T, true, false, 1>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+    else if (wide) hipLaunchKernelGGL((k_tile<T, false, true, 1>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+    else hipLaunchKernelGGL((k_tile<T, false, false, 1>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+  }
   prof.done(stream);
   HIP_TRY(hipGetLastError());
 #ifdef QSIM_PROBES
