@@ -102,12 +102,6 @@ class HipShardBackend:
     def apply_ops(self, ops) -> int:
         return self.chunk("state").apply_ops(ops)      # HBM passes (fused tile launches)
 
-    def pack_bits(self, bits, pattern: int, dst: str, dst_offset: int) -> None:
-        self.chunk("state").pack_bits(bits, pattern, self.chunk(dst), dst_offset)
-
-    def unpack_bits(self, bits, pattern: int, src: str, src_offset: int) -> None:
-        self.chunk("state").unpack_bits(bits, pattern, self.chunk(src), src_offset)
-
     def pack_all(self, bits, dst: str, skip_pattern: int, piece: int = 0, n_pieces: int = 1) -> None:
         self.chunk("state").pack_all(bits, self.chunk(dst), skip_pattern, piece, n_pieces)
 
@@ -253,9 +247,6 @@ class DistributedEngine:
     def _rank_bit(self, phys_qubit: int) -> int:
         return (self.rank >> (phys_qubit - self.k)) & 1
 
-    def _partner(self, phys_qubit: int) -> int:
-        return self.rank ^ (1 << (phys_qubit - self.k))
-
     def _post(self, transfers):
         """Post [(peer, send_tensor, recv_tensor)] together, without waiting (RCCL: the transfer is
         ordered after everything already queued on the current stream)."""
@@ -303,14 +294,6 @@ class DistributedEngine:
             timer[1].record()
             self._comm_events.append(timer)
         self.exchanges += 1
-
-    def _exchange(self, transfers) -> None:
-        """transfers: [(peer, send_tensor, recv_tensor)], all posted together, then awaited."""
-        if not transfers:
-            return
-        timer = self._comm_timer(transfers[0][1])
-        self._finish(self._post(transfers))
-        self._comm_done(timer)
 
     # ---- deferred local work -------------------------------------------------------------------
     # Global-qubit gates that need no exchange end up as LOCAL ops on this rank (a rank-bit phase,

@@ -48,14 +48,6 @@ class CpuShardBackend:
             keep &= ((idx >> b) & 1) == ((pattern >> i) & 1)
         return idx[keep]
 
-    def pack_bits(self, bits, pattern: int, dst: str, dst_offset: int) -> None:
-        sel = self._slab_index(bits, pattern)
-        self._c(dst)[dst_offset:dst_offset + sel.size] = self._c("state")[sel]
-
-    def unpack_bits(self, bits, pattern: int, src: str, src_offset: int) -> None:
-        sel = self._slab_index(bits, pattern)
-        self._c("state")[sel] = self._c(src)[src_offset:src_offset + sel.size]
-
     def pack_all(self, bits, dst: str, skip_pattern: int, piece: int = 0, n_pieces: int = 1) -> None:
         slab = 1 << (self.k - len(bits))
         part = slab // n_pieces
