@@ -512,6 +512,10 @@ def c_string(lines) -> str:
 
 
 def main():
+    probes = sorted(k for k in os.environ if k.startswith("QS_GEN_") and k != "QS_GEN_ALLOW_PROBES")
+    if probes and os.environ.get("QS_GEN_ALLOW_PROBES") != "1":
+        sys.exit(f"gen_tile_engine.py: probe options {probes} are set; they change (some of them break) the engine. "
+                 "Set QS_GEN_ALLOW_PROBES=1 for an A/B build, never for the committed header.")
     out = sys.stdout
     out.write("// tile_engine_gen.h -- GENERATED by gen_tile_engine.py (do not edit): the gate engine of k_tile\n"
               "// as one gfx950 inline-asm block.  See the generator for the design and the register map.\n"
