@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--sustain-seconds", type=float, default=3.0,
                     help="second, longer timed region after the K-step one (0 = off)")
     ap.add_argument("--no-configs", action="store_true", help="N > 1: skip the config-4 / config-5 sub-runs")
+    ap.add_argument("--no-single-reference", action="store_true",
+                    help="N > 1: skip the one-GPU run at the same local size on rank 0")
     ap.add_argument("--dry-run", action="store_true",
                     help="N > 1: print and cross-check the communication schedule only (gloo, no shard memory)")
     return ap.parse_args()
@@ -237,6 +239,7 @@ def run_single(args, k: int) -> tuple[dict, list[str]]:
                    "n_qubits": n, "local_qubits": k, "gates_per_step": n_gates, "mode": args.mode,
                    "hbm_passes_per_step": passes},
         "timed_seconds": round(dt, 4),
+        "amplitude_updates_per_s": n_gates * args.steps * float(1 << n) / dt,
         "sustained": sustained,
         "norm2_after": norm2,
         "roofline": roofline,
@@ -313,12 +316,38 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
         c4 = configs.get("config4")
         if c4 and abs(c4["staged"]["norm2"] - 1.0) > NORM_TOL:
             invalid.append("config 4: norm check failed")
+    # the same workload family on ONE GPU at the same local size (rank 0, outside the timed region, the other
+    # ranks wait): per-GPU work is what weak scaling holds fixed, and the N = 1 default of this script is the
+    # 28-qubit metric configuration, not a 30-local-qubit one
+    single = None
+    if rank == 0 and not args.no_single_reference:
+        from quantum_simulations_amd.runner.engine import SingleGpuEngine
+        e1 = SingleGpuEngine(k, device=local_rank, mode=args.mode)
+        c1 = gen.random_1q_cx_circuit(k, depth=args.depth)
+        e1.init_zero_state()
+        reps1 = max(3, min(args.steps, 5))
+        p1 = e1.plan(c1, repeats=2 + reps1)
+        for _ in range(2):
+            e1.execute(p1)
+        e1.barrier()
+        t1 = time.perf_counter()
+        for _ in range(reps1):
+            e1.execute(p1)
+        e1.barrier()
+        dt1 = time.perf_counter() - t1
+        single = {"n_qubits": k, "gates_per_step": len(c1["gates"]), "steps": reps1,
+                  "ms_per_step": round(dt1 / reps1 * 1e3, 3), "hbm_passes_per_step": e1.passes_per_step(p1),
+                  "gate_apps_per_s": round(len(c1["gates"]) * reps1 / dt1, 2),
+                  "amplitude_updates_per_s": len(c1["gates"]) * reps1 * float(1 << k) / dt1}
+        e1.close()
+    engine.barrier()
     if rank != 0:
         engine.close()
         return None, invalid
 
     dom = max(prof, key=lambda e: e["total_ms"]) if prof else None
     roofline = None
+    kernel_ms = sum(e["total_ms"] for e in prof)
     if dom:
         secs = dom["total_ms"] * 1e-3
         moved = dom["hbm_bytes"] / secs / 1e9
@@ -344,6 +373,11 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
                                 "unit at every N; per-GPU shard work is fixed, so this is weak scaling)"},
         "timed_seconds": round(dt, 4),
         "shard_gate_apps_per_s": round(n_gates * world * args.steps / dt, 2),
+        # gates x amplitudes of the whole state per second: the size-independent throughput (weak scaling holds
+        # the per-GPU share of it fixed); next to it the same on ONE GPU at the same local size, same job
+        "amplitude_updates_per_s": n_gates * args.steps * float(1 << n) / dt,
+        "single_gpu_same_local_size": single,
+        "rank0_gate_kernel_time_share": round(kernel_ms * 1e-3 / dt, 4),
         "norm2_after": norm2,
         "roofline": roofline,
         "xgmi": xgmi,
