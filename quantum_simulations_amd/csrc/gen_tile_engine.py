@@ -54,8 +54,8 @@ PAD_AFTER = os.environ.get("QS_GEN_PAD_AFTER", "")      # ... the same after the
 # ---- entry numbers (header dword 0 = 4 * entry); the gate families keep the r01 opcode numbers ----
 OPC = dict(NOP=0, DENSE1=1, SWAP1=10, ANTI1=19, PHASE=28, DENSE2=36, REAL1=45, YLIKE1=54,
            PHASE_NEG=63, PHASE_I=71, PHASE_NI=79, DIAGR=87,
-           PRED_OUTER=91, PRED_LANE=92, GROUP=93, GROUP_FIRST=94, END=95, HAD1=96, SCALE=105)
-NENT = 106
+           PRED_OUTER=91, PRED_LANE=92, GROUP=93, GROUP_FIRST=94, END=95, HAD1=96, SCALE=105, ASWAP1=106)
+NENT = 115
 
 BANK = {"A": 36, "B": 52}                # s32 (the ABI stack pointer) is reserved: banks start at s36
 E = 68                                   # overflow bank s[68:83]
@@ -236,6 +236,14 @@ def body_swap(a, bank, pairs):
             a(f"v_swap_b32 {XD(pa, c)}, {XD(pb, c)}")
 
 
+def body_aswap(a, bank, pairs):
+    """X / CNOT deferred to the write-back: the LDS ADDRESSES of the pair trade places (one v_swap_b32 per pair
+    instead of four on the data).  The host uses it only when nothing later in the group touches the target
+    (or a register control): the registers then reach LDS at the swapped positions."""
+    for pa, pb in pairs:
+        a(f"v_swap_b32 {A(pa)}, {A(pb)}")
+
+
 def body_ylike(a, bank, pairs):
     """[[0,-i],[i,0]]: x_a' = -i x_b = (b.y, -b.x), x_b' = i x_a = (-a.y, a.x)"""
     for pa, pb in pairs:
@@ -348,7 +356,7 @@ def gate_cases():
     """entry -> function(asm, bank) emitting the straight-line body"""
     cases = {}
     for fam, body in (("DENSE1", body_dense1), ("SWAP1", body_swap), ("ANTI1", body_anti), ("REAL1", body_real),
-                      ("YLIKE1", body_ylike), ("HAD1", body_had)):
+                      ("YLIKE1", body_ylike), ("HAD1", body_had), ("ASWAP1", body_aswap)):
         for var in range(9):
             cases[OPC[fam] + var] = (f"{fam.lower()}_{var}", lambda a, bank, body=body, var=var: body(a, bank, PAIRS[var]))
     for fam, body in (("PHASE", body_phase), ("PHASE_NEG", body_phase_neg), ("PHASE_I", body_phase_i),

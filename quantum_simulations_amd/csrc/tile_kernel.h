@@ -57,7 +57,10 @@ enum : uint8_t {
   OPC_END = QS_ENT_END,
   OPC_HAD1 = QS_ENT_HAD1,             // +variant 0..2 (no control): a' = a + b, b' = a - b          H     (0)
                                       // the factor c of c [[1,1],[1,-1]] is collected over the pass and applied by
-  OPC_SCALE = QS_ENT_SCALE            // every amplitude times a real factor (1 double), last record of the pass
+  OPC_SCALE = QS_ENT_SCALE,           // every amplitude times a real factor (1 double), last record of the pass
+  OPC_ASWAP1 = QS_ENT_ASWAP1          // +variant: OPC_SWAP1 deferred to the group's write-back -- the LDS addresses of the
+                                      // pair trade places (1 instruction per pair instead of 4); only when nothing later
+                                      // in the group touches the target or a register control          (0)
 };
 // 1q variant: 0..2 = target register bit J, no register control; 3 + 2*J + k = control on the
 // k-th of the two other register bits (ascending)

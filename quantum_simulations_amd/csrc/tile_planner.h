@@ -338,7 +338,13 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
       }
       emit(d);
     };
+    // qubits touched by the ops AFTER position i of the group (X / CNOT that nothing later touches are sunk
+    // into the write-back: OPC_ASWAP1)
+    std::vector<u64> later(grp.size() + 1, 0);
+    for (size_t i = grp.size(); i-- > 0;) later[i] = later[i + 1] | op_qmask(ops[members[grp[i]]]);
+    size_t gi = 0;
     for (size_t mi : grp) {
+      const u64 touched_later = later[++gi];
       const FusedOp& o = ops[members[mi]];
       TileDesc d;
       std::memset(&d, 0, sizeof d);
@@ -390,6 +396,9 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
         const int J = reg_pos(tile_pos(o.target[0]));
         if (o.control >= 0) require_one(o.control);
         d.opcode = (uint8_t)(shape.family + opc_1q_variant(J, ctrl_reg));
+        if (shape.family == OPC_SWAP1 && tuning().tile_sink_swaps &&
+            !(touched_later & (1ull << o.target[0])) && !(ctrl_reg >= 0 && (touched_later & (1ull << o.control))))
+          d.opcode = (uint8_t)(OPC_ASWAP1 + opc_1q_variant(J, ctrl_reg));
         if (shape.family == OPC_HAD1) {
           pass_scale *= o.m[0].x;
         } else if (shape.family == OPC_REAL1) {
@@ -413,13 +422,26 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
     else used -= kGroupRecordBytes;
     if (cut) break;                   // record budget exhausted inside the group
   }
-  if (pass_scale != 1.0 && !out->empty()) {   // a global factor commutes with everything: once, at the end
-    TileDesc d;
-    std::memset(&d, 0, sizeof d);
-    d.opcode = OPC_SCALE;
-    d.m[0] = pass_scale;
-    d.nd = 1;
-    out->back().gates.push_back(d);
+  if (pass_scale != 1.0 && !out->empty()) {   // a global factor commutes with everything: applied once
+    // ... for free when the pass has an unconditional dense / real / anti-diagonal 1q gate (every amplitude goes
+    // through its matrix: scale the matrix); else as one OPC_SCALE record at the end
+    TileDesc* host = nullptr;
+    for (TileGroup& g : *out)
+      for (TileDesc& d : g.gates) {
+        const bool fam = (d.opcode >= OPC_REAL1 && d.opcode < OPC_REAL1 + 3) || (d.opcode >= OPC_DENSE1 && d.opcode < OPC_DENSE1 + 3) ||
+                         (d.opcode >= OPC_ANTI1 && d.opcode < OPC_ANTI1 + 3);      // variants 0..2: no register control
+        if (fam && !d.blk_mask && !d.outer_mask && !host) host = &d;
+      }
+    if (host) {
+      for (int e = 0; e < host->nd; ++e) host->m[e] *= pass_scale;
+    } else {
+      TileDesc d;
+      std::memset(&d, 0, sizeof d);
+      d.opcode = OPC_SCALE;
+      d.m[0] = pass_scale;
+      d.nd = 1;
+      out->back().gates.push_back(d);
+    }
   }
 }
 

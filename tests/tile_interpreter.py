@@ -19,9 +19,9 @@ IMAGE_BYTES = 4096
 STREAM_OFF = 32                    # byte offset of the first record (csrc/tile_kernel.h)
 OPC = dict(DENSE1=1, SWAP1=10, ANTI1=19, PHASE=28, DENSE2=36, REAL1=45, YLIKE1=54, PHASE_NEG=63,
            PHASE_I=71, PHASE_NI=79, DIAGR=87, PRED_OUTER=91, PRED_LANE=92, GROUP=93, GROUP_FIRST=94, END=95,
-           HAD1=96, SCALE=105)
+           HAD1=96, SCALE=105, ASWAP1=106)
 _FAMILIES = ("DENSE1", "SWAP1", "ANTI1", "PHASE", "DENSE2", "REAL1", "YLIKE1", "PHASE_NEG", "PHASE_I", "PHASE_NI", "DIAGR",
-             "HAD1", "SCALE")
+             "HAD1", "SCALE", "ASWAP1")
 _IMAGE = np.dtype([("amp", "<u8"), ("nrec", "<i4"), ("T", "<i4"), ("h", "u1", (11,)), ("order", "u1"), ("ntiles", "<u4"),
                    ("stream", "u1", (IMAGE_BYTES - STREAM_OFF,))])
 assert _IMAGE.itemsize == IMAGE_BYTES
@@ -138,8 +138,16 @@ def run_pass(psi: np.ndarray, img) -> int:
     run = 0
     A = None
     s = None
+    sunk = []            # OPC_ASWAP1 gates of the current group: they act when the registers are written back
+
+    def write_back():
+        for t_bit, cond_mask in sunk:
+            _apply_1q(psi, idx, t_bit, np.array([[0, 1], [1, 0]], dtype=complex), cond_mask)
+        sunk.clear()
+
     for rec in records(img):
         if rec[0] == "group":
+            write_back()
             s = rec[1]
             assert s[0] < s[1] < s[2] < T, s
             A = [abs_bit(b) for b in s]                                 # absolute index bit of register bit j
@@ -153,6 +161,16 @@ def run_pass(psi: np.ndarray, img) -> int:
         if fam == OPC["SCALE"]:
             assert var == 0 and not cond and size == 32
             psi *= float(dbl(0, 1)[0])
+        elif fam == OPC["ASWAP1"]:
+            # deferred X / CNOT: the device swaps LDS addresses, the data moves at the group's write-back -- applied
+            # THERE here too, so a gate the planner sank although something later does not commute with it shows
+            assert 0 <= var < 9 and size == 16
+            if var < 3:
+                J, ctrl = var, None
+            else:
+                J, kk = (var - 3) // 2, (var - 3) % 2
+                ctrl = [r for r in range(3) if r != J][kk]
+            sunk.append((A[J], cond | (0 if ctrl is None else 1 << A[ctrl])))
         elif fam in (OPC["DENSE1"], OPC["SWAP1"], OPC["ANTI1"], OPC["REAL1"], OPC["YLIKE1"], OPC["HAD1"]):
             assert 0 <= var < 9
             if var < 3:
@@ -219,6 +237,7 @@ def run_pass(psi: np.ndarray, img) -> int:
         else:
             raise AssertionError(f"unknown opcode {op}")
         run += 1
+    write_back()
     return run
 
 
