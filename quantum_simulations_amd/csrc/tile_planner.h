@@ -320,13 +320,33 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
       d.blk_mask = acc.blk;
       d.outer_mask = acc.outer;
       double2 m[3];
-      int nm = 0;
-      for (int r = 0; r < 3; ++r) if (acc.touched & (1u << r)) m[nm++] = acc.phi[r];
+      int nm = 0, regs[3];
+      for (int r = 0; r < 3; ++r) if (acc.touched & (1u << r)) { regs[nm] = r; m[nm++] = acc.phi[r]; }
       auto put = [&](int at, double2 v) { d.m[2 * at] = v.x; d.m[2 * at + 1] = v.y; };
-      if (nm == 1) {
-        d.opcode = (uint8_t)(OPC_PHASE + acc.touched);
-        put(0, m[0]); d.nd = 2;
-      } else if (nm == 2) {
+      // one phase on one register bit: -1 / i / -i have their own families (2 / 3 / 3 vector instructions per
+      // register instead of 4)
+      auto single = [&](int r, double2 v) {
+        TileDesc s1 = d;
+        const bool sp = tuning().tile_special;
+        const int fam = (sp && v.x == -1 && v.y == 0) ? OPC_PHASE_NEG : (sp && v.x == 0 && v.y == 1) ? OPC_PHASE_I
+                        : (sp && v.x == 0 && v.y == -1) ? OPC_PHASE_NI : OPC_PHASE;
+        s1.opcode = (uint8_t)(fam + (1u << r));
+        if (fam == OPC_PHASE) { s1.m[0] = v.x; s1.m[1] = v.y; s1.nd = 2; }
+        emit(s1);
+      };
+      auto cost1 = [&](double2 v) {   // vector instructions of the single form (4 registers)
+        if (!tuning().tile_special) return 16;
+        return (v.x == -1 && v.y == 0) ? 8 : ((v.x == 0 && (v.y == 1 || v.y == -1)) ? 12 : 16);
+      };
+      if (nm == 1) { single(regs[0], m[0]); return; }
+      // merged run: 6 (two bits) or 7 (three bits) registers x 4 instructions, one record instead of nm
+      int separate = 0;
+      for (int e = 0; e < nm; ++e) separate += cost1(m[e]);
+      if (separate < (nm == 2 ? 24 : 28)) {
+        for (int e = 0; e < nm; ++e) single(regs[e], m[e]);
+        return;
+      }
+      if (nm == 2) {
         d.opcode = (uint8_t)(OPC_DIAGR + (acc.touched == 3 ? 0 : acc.touched == 5 ? 1 : 2));
         put(0, m[0]); put(1, m[1]); put(2, cmul2(m[0], m[1])); d.nd = 6;
       } else {                          // a, b, c | ab, ac, bc, abc
@@ -362,7 +382,7 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
           // phase may grow a run to its largest form)
         int reserve = 0;
         for (const Acc& acc : open) reserve += run_bytes(acc.touched);
-        const bool mergeable = merge_on && shape.family == OPC_PHASE;
+        const bool mergeable = merge_on && o.kind == TG_PHASE;
         if (used + reserve + (mergeable ? desc_bytes(14) : desc_bytes(shape.nd)) > kTileRecordBudget) { cut = true; break; }
       }
       done[mi] = 1;
@@ -372,7 +392,7 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
       if (o.kind == TG_PHASE) {
         for (int t = 0; t < o.nbits; ++t) require_one(o.bits[t]);
         d.opcode = (uint8_t)(shape.family + reg_mask);
-        if (merge_on && shape.family == OPC_PHASE && __builtin_popcount(reg_mask) == 1) {
+        if (merge_on && __builtin_popcount(reg_mask) == 1) {   // (every phase family: -1 / +-i join the runs too)
           const int r = __builtin_ctz(reg_mask);
           size_t i = 0;
           while (i < open.size() && !(open[i].blk == d.blk_mask && open[i].outer == d.outer_mask)) ++i;
