@@ -24,7 +24,9 @@ block (tile_kernel.h, `TileArgs::stream`):
     seven XOR constants of the swizzled LDS addresses (the swizzle t ^ ((t >> 4) & 15) is linear
     over GF(2), so slot(tb | b) = slot(tb) ^ slot(b) with slot(b) wave-uniform).
 
-Fixed registers (listed as clobbers of the asm statement):
+Fixed registers (clobbers of the asm statement, except x0..x7: in/out operands pinned to v[4:35], because the
+first / last register group of a pass may be the layout the kernel loads / stores in -- GROUP_DIRECT starts
+from the operands' values without reading LDS, END_DIRECT leaves the result in them without writing it):
   v[4:35]   x0..x7 (complex128 each: .x = v[4+4j:5+4j], .y = v[6+4j:7+4j])
   v[36:43]  LDS byte addresses of x0..x7      v44 tb (thread's tile index with the group bits 0)
   v45 scratch   v[46:61] eight f64 temporaries   (the thread id is read from the operand's register)
@@ -54,8 +56,9 @@ PAD_AFTER = os.environ.get("QS_GEN_PAD_AFTER", "")      # ... the same after the
 # ---- entry numbers (header dword 0 = 4 * entry); the gate families keep the r01 opcode numbers ----
 OPC = dict(NOP=0, DENSE1=1, SWAP1=10, ANTI1=19, PHASE=28, DENSE2=36, REAL1=45, YLIKE1=54,
            PHASE_NEG=63, PHASE_I=71, PHASE_NI=79, DIAGR=87,
-           PRED_OUTER=91, PRED_LANE=92, GROUP=93, GROUP_FIRST=94, END=95, HAD1=96, SCALE=105, ASWAP1=106)
-NENT = 115
+           PRED_OUTER=91, PRED_LANE=92, GROUP=93, GROUP_FIRST=94, END=95, HAD1=96, SCALE=105, ASWAP1=106,
+           GROUP_DIRECT=115, END_DIRECT=116)
+NENT = 117
 
 BANK = {"A": 36, "B": 52}                # s32 (the ABI stack pointer) is reserved: banks start at s36
 E = 68                                   # overflow bank s[68:83]
@@ -431,6 +434,10 @@ def engine(partial: bool) -> list[str]:
                 a(f"s_branch {lab('group_' + bank)}")
             elif e == OPC["GROUP_FIRST"]:
                 a(f"s_branch {lab('group_first_' + bank)}")
+            elif e == OPC["GROUP_DIRECT"]:
+                a(f"s_branch {lab('group_direct_' + bank)}")
+            elif e == OPC["END_DIRECT"]:
+                a(f"s_branch {lab('end_direct')}")
             else:                          # END and unused entries
                 a(f"s_branch {lab('end')}")
     a.label("start")
@@ -472,23 +479,30 @@ def engine(partial: bool) -> list[str]:
         if partial:
             a("s_mov_b64 exec, -1")
         a("s_nop 0" if NOBARRIER else "s_barrier")
+        def addresses():
+            # record dwords: 2..4 = insert-zero masks (~0 << s_i, ascending), 5..11 = XOR constants of x1..x7
+            a(f"v_and_b32 {VT}, {HD(bank, 2)}, {TID}")
+            a(f"v_add_u32 {TB}, {TID}, {VT}")
+            a(f"v_and_b32 {VT}, {HD(bank, 3)}, {TB}")
+            a(f"v_add_u32 {TB}, {TB}, {VT}")
+            a(f"v_and_b32 {VT}, {HD(bank, 4)}, {TB}")
+            a(f"v_add_u32 {TB}, {TB}, {VT}")
+            a(f"v_bfe_u32 {VT}, {TB}, 4, 4")
+            a(f"v_xor_b32 {A(0)}, {VT}, {TB}")
+            a(f"v_lshlrev_b32 {A(0)}, 4, {A(0)}")
+            for j in range(1, 8):
+                a(f"v_xor_b32 {A(j)}, {HD(bank, 4 + j)}, {A(0)}")
         a.label("group_first_" + bank)
-        # record dwords: 2..4 = insert-zero masks (~0 << s_i, ascending), 5..11 = XOR constants of x1..x7
-        a(f"v_and_b32 {VT}, {HD(bank, 2)}, {TID}")
-        a(f"v_add_u32 {TB}, {TID}, {VT}")
-        a(f"v_and_b32 {VT}, {HD(bank, 3)}, {TB}")
-        a(f"v_add_u32 {TB}, {TB}, {VT}")
-        a(f"v_and_b32 {VT}, {HD(bank, 4)}, {TB}")
-        a(f"v_add_u32 {TB}, {TB}, {VT}")
-        a(f"v_bfe_u32 {VT}, {TB}, 4, 4")
-        a(f"v_xor_b32 {A(0)}, {VT}, {TB}")
-        a(f"v_lshlrev_b32 {A(0)}, 4, {A(0)}")
-        for j in range(1, 8):
-            a(f"v_xor_b32 {A(j)}, {HD(bank, 4 + j)}, {A(0)}")
+        addresses()
         if partial:
             a("s_mov_b64 exec, s[28:29]")
         for j in range(8):
             a(f"ds_read_b128 {X(j)[2]}, {A(j)}")
+        a(f"s_branch {lab('top_' + other(bank))}")
+        # ---- first group = the layout the kernel loaded in: x0..x7 hold it already, only the addresses of
+        # the write-back are needed ----
+        a.label("group_direct_" + bank)
+        addresses()
         a(f"s_branch {lab('top_' + other(bank))}")
         # ---- gate bodies ----
         for e in sorted(cases):
@@ -507,11 +521,14 @@ def engine(partial: bool) -> list[str]:
     a("s_mov_b64 exec, -1")
     a("s_waitcnt lgkmcnt(0)")
     a("s_barrier")
+    # ---- END_DIRECT: the last group is the layout the kernel stores in; the result stays in x0..x7 ----
+    a.label("end_direct")
+    a("s_mov_b64 exec, -1")
     return a.lines
 
 
 def clobbers() -> str:
-    regs = [f"v{i}" for i in range(4, 62)] + [f"s{i}" for i in range(16, 30)] + [f"s{i}" for i in range(36, 84)] + ["vcc", "scc", "memory"]
+    regs = [f"v{i}" for i in range(36, 62)] + [f"s{i}" for i in range(16, 30)] + [f"s{i}" for i in range(36, 84)] + ["vcc", "scc", "memory"]
     return ", ".join(f'"{r}"' for r in regs)
 
 

@@ -58,9 +58,12 @@ enum : uint8_t {
   OPC_HAD1 = QS_ENT_HAD1,             // +variant 0..2 (no control): a' = a + b, b' = a - b          H     (0)
                                       // the factor c of c [[1,1],[1,-1]] is collected over the pass and applied by
   OPC_SCALE = QS_ENT_SCALE,           // every amplitude times a real factor (1 double), last record of the pass
-  OPC_ASWAP1 = QS_ENT_ASWAP1          // +variant: OPC_SWAP1 deferred to the group's write-back -- the LDS addresses of the
+  OPC_ASWAP1 = QS_ENT_ASWAP1,         // +variant: OPC_SWAP1 deferred to the group's write-back -- the LDS addresses of the
                                       // pair trade places (1 instruction per pair instead of 4); only when nothing later
                                       // in the group touches the target or a register control          (0)
+  OPC_GROUP_DIRECT = QS_ENT_GROUP_DIRECT,   // first group = the layout the kernel loaded the tile in (TileArgs::lay_in):
+                                      // x0..x7 arrive in registers, no LDS read
+  OPC_END_DIRECT = QS_ENT_END_DIRECT  // last group = the layout the kernel stores in (lay_out): no LDS write-back
 };
 // 1q variant: 0..2 = target register bit J, no register control; 3 + 2*J + k = control on the
 // k-th of the two other register bits (ascending)
@@ -74,11 +77,11 @@ static inline int opc_1q_variant(int J, int C) {
 //           d1 = byte offset of the next record from the start of the kernel arguments,
 //           d2 = outer predicate (absolute index bits >> kTileLow that must be 1),
 //           d3 = lane predicate (tile bits, low half) | 4 x case entry << 16 (second dispatch of a predicated gate)
-//   group:  d0 = 4 x OPC_GROUP(_FIRST), d1 = next, d2..d4 = ~0 << s_i for the group's tile bits s_0 < s_1 < s_2,
+//   group:  d0 = 4 x OPC_GROUP(_FIRST / _DIRECT), d1 = next, d2..d4 = ~0 << s_i for the group's tile bits s_0 < s_1 < s_2,
 //           d5..d11 = LDS byte-address XOR constants of registers x1..x7 (lds_slot is linear over GF(2))
-//   end:    d0 = 4 x OPC_END, d1 = its own offset
+//   end:    d0 = 4 x OPC_END(_DIRECT), d1 = its own offset
 constexpr int kTileArgBytes = 4096;
-constexpr int kTileStreamOff = 32;                       // byte offset of the first record
+constexpr int kTileStreamOff = 48;                       // byte offset of the first record
 constexpr int kTileStreamBytes = kTileArgBytes - kTileStreamOff;
 constexpr int kTileStreamSlack = 48;                     // the 64-byte fetch of the END record stays inside the block
 
@@ -87,10 +90,19 @@ struct TileArgs {
   int nrec;                // records in the stream incl. END (host bookkeeping; the device follows the stream)
   int T;                   // tile size of the pass (read by the pass-image consumers; the kernel is a template)
   uint8_t h[11];           // ascending absolute positions of the tile's high bits
-  uint8_t order;           // tile order of the launch: 0 consecutive, 1 hashed, 2 bit-reversed (see k_tile)
+  uint8_t order;           // bits 0-1: tile order of the launch: 0 consecutive, 1 hashed, 2 bit-reversed (see k_tile);
+                           // kTileDirectIn / kTileDirectOut: the tile goes global <-> registers without LDS
   uint32_t ntiles;         // 2^(k - T)
+  // Thread layout of the global loads / stores: element j of thread tid is index bits
+  //   (tid & 7) | sum_i bit(tid, 3 + i) << lay[i]  (i < 5)  |  sum_b bit(j, b) << lay[5 + b].
+  // Through LDS (no direct flag) both are h[0..7] in order (element tid + 256 j of the tile).  Direct: lay_in[5..7] are
+  // the bits of the FIRST register group (all above the line bits), lay_in[0..4] the other tile bits ascending --
+  // what the thread then holds IS the group's x0..x7; lay_out likewise for the LAST group.
+  uint8_t lay_in[8];
+  uint8_t lay_out[8];
   uint32_t stream[kTileStreamBytes / 4];
 };
+constexpr uint8_t kTileDirectIn = 0x10, kTileDirectOut = 0x20, kTileOrderMask = 0x03;
 static_assert(sizeof(TileArgs) == kTileArgBytes, "kernel arguments are one 4 KiB block");
 static_assert(offsetof(TileArgs, stream) == kTileStreamOff, "record offsets are relative to the argument block");
 
@@ -139,24 +151,32 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
   int hs[NH];                                         // the tile's high bits, pinned to scalar registers
 #pragma unroll
   for (int j = 0; j < NH; ++j) hs[j] = __builtin_amdgcn_readfirstlane((int)a.h[j]);
-  using off_t = typename std::conditional<WIDE, u64, unsigned>::type;   // !WIDE: every h[i] used here is < 28
-  // element t = tid + BLOCK * j -> row = (tid >> LOW) | (j << (TB - LOW)): the thread part of the
-  // offset is computed once, the j part is wave-uniform (scalar registers)
-  off_t off_tid = tid & ((1 << LOW) - 1);
+  using off_t = typename std::conditional<WIDE, u64, unsigned>::type;   // !WIDE: every thread-part bit is < 28
+  constexpr int NTB = (TB - LOW) < NH ? (TB - LOW) : NH;                // tile high bits that are thread bits
+  const bool din = (a.order & kTileDirectIn) != 0, dout = (a.order & kTileDirectOut) != 0;   // (uniform)
+  // element j of thread tid in a layout `lay` (TileArgs::lay_in / lay_out): the thread part of the offset is
+  // computed once per kernel, the j part is wave-uniform (scalar registers)
+  auto thread_off = [&](const uint8_t* lay) -> off_t {
+    off_t o = tid & ((1 << LOW) - 1);
 #pragma unroll
-  for (int i = 0; i < TB - LOW && i < NH; ++i) off_tid |= (off_t)((tid >> (LOW + i)) & 1) << hs[i];
-  auto off_j = [&](int j) -> u64 {
-    u64 o = 0;
-#pragma unroll
-    for (int i = TB - LOW; i < NH; ++i) o |= (u64)((j >> (i - (TB - LOW))) & 1) << hs[i];
+    for (int i = 0; i < NTB; ++i) o |= (off_t)((tid >> (LOW + i)) & 1) << __builtin_amdgcn_readfirstlane((int)lay[i]);
     return o;
   };
+  const off_t tin = thread_off(a.lay_in), tout = thread_off(a.lay_out);
+  int rin[NH - NTB + 1], rout[NH - NTB + 1];          // (+1: no zero-length arrays)
+#pragma unroll
+  for (int i = NTB; i < NH; ++i) {
+    rin[i - NTB] = __builtin_amdgcn_readfirstlane((int)a.lay_in[i]);
+    rout[i - NTB] = __builtin_amdgcn_readfirstlane((int)a.lay_out[i]);
+  }
   // Which tile a workgroup takes: TPW consecutive tiles per workgroup; order 0 = consecutive tiles in flight,
   // 1 = hashed, 2 = bit-reversed (probe build only, see tile_order_for).  ntiles is a power of two.
   auto tile_base = [&](unsigned i) -> u64 {
     unsigned tile = blockIdx.x * TPW + i;
-    if (a.order == 1) tile = (tile * 0x9E3779B1u) & (a.ntiles - 1);
-    if (a.order == 2) tile = a.ntiles > 1 ? __brev(tile) >> (__clz(a.ntiles) + 1) : 0;
+#ifdef QSIM_PROBES
+    if ((a.order & kTileOrderMask) == 1) tile = (tile * 0x9E3779B1u) & (a.ntiles - 1);
+    if ((a.order & kTileOrderMask) == 2) tile = a.ntiles > 1 ? __brev(tile) >> (__clz(a.ntiles) + 1) : 0;
+#endif
     u64 base = (u64)tile << LOW;                      // the tile number enumerates the non-tile bits
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
@@ -165,52 +185,72 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
     }
     return base;
   };
-  auto element = [&](u64 base, int j) -> double2* {
+  typedef double amp_t __attribute__((ext_vector_type(2)));   // one amplitude as a 128-bit register operand of the engine
+  typedef __attribute__((address_space(1))) amp_t gamp_t;     // ... in global memory: global_*, not flat_* (a flat access
+                                                              // also counts on lgkmcnt, which the engine waits on per record)
+  auto element = [&](u64 base, int j, off_t toff, const int* rbits) -> gamp_t* {
+    u64 oj = 0;
+#pragma unroll
+    for (int i = 0; i < NH - NTB; ++i) oj |= (u64)((j >> i) & 1) << rbits[i];
     if constexpr (WIDE) {
-      return a.amp + base + off_tid + off_j(j);
+      return (gamp_t*)(u64)(a.amp + base + toff + oj);
     } else {
       // wave-uniform row base pinned to scalar registers + 32-bit thread offset: `global_* v, voff, s[row]`,
       // no 64-bit vector address is formed (or kept alive across the engine)
-      const u64 r = reinterpret_cast<u64>(a.amp + base + off_j(j));
+      const u64 r = reinterpret_cast<u64>(a.amp + base + oj);
       const u64 row = ((u64)__builtin_amdgcn_readfirstlane((unsigned)(r >> 32)) << 32) |
                       (unsigned)__builtin_amdgcn_readfirstlane((unsigned)r);
-      return reinterpret_cast<double2*>(reinterpret_cast<char*>(row) + (off_tid << 4));
+      unsigned tb = toff << 4;
+      asm volatile("" : "+v"(tb));   // (opaque: otherwise the zero-extended 64-bit form is kept alive across the engine and spilled)
+      return (gamp_t*)((__attribute__((address_space(1))) char*)row + tb);
     }
   };
+  auto load = [&](gamp_t* p) -> amp_t { return NT ? __builtin_nontemporal_load(p) : *p; };
+  auto store = [&](gamp_t* p, amp_t v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; };
   const unsigned slot0 = lds_slot(tid);               // element tid + BLOCK * j sits BLOCK * j slots further (the swizzle uses bits 4-7 only)
   static_assert(BLOCK >= 256, "lds_slot(tid + BLOCK * j) = lds_slot(tid) + BLOCK * j needs BLOCK to be a multiple of 256");
+  amp_t* const tile = reinterpret_cast<amp_t*>(lds);
   u64 base = tile_base(0);
-  double2 v[PER];
+  amp_t v[PER];
 #pragma unroll
-  for (int j = 0; j < PER; ++j) v[j] = ld_amp<NT>(element(base, j));
+  for (int j = 0; j < PER; ++j) v[j] = load(element(base, j, tin, rin));
 #pragma unroll 1
   for (int it = 0; it < TPW; ++it) {                  // (rolled: one copy of the 92 KiB engine)
+    // the engine's x0..x7 (pinned to v[4:35]): the loaded tile itself when the first register group is the load
+    // layout (din: the stream starts with OPC_GROUP_DIRECT), otherwise overwritten by the first group's LDS read
+    amp_t x[8];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) lds[slot0 + BLOCK * j] = v[j];
-    __syncthreads();
+    for (int j = 0; j < 8; ++j) x[j] = j < PER ? v[j < PER ? j : 0] : amp_t{0.0, 0.0};
+    if (!din) {
+#pragma unroll
+      for (int j = 0; j < PER; ++j) tile[slot0 + BLOCK * j] = v[j];
+      __syncthreads();
+    }
     // TPW > 1: the NEXT tile's loads are issued before the gate engine runs and land while it works (the
     // engine issues no vector-memory operation and waits for none)
     const u64 cur = base;
     if (it + 1 < TPW) {
       base = tile_base(it + 1);
 #pragma unroll
-      for (int j = 0; j < PER; ++j) v[j] = ld_amp<NT>(element(base, j));
+      for (int j = 0; j < PER; ++j) v[j] = load(element(base, j, tin, rin));
     }
 #ifdef QSIM_PROBES
     if (it == 0) t_loaded = __builtin_readcyclecounter();
 #endif
-    // ---- gate engine: interprets a.stream on the tile in LDS; returns after its last barrier ----
+    // ---- gate engine: interprets a.stream on the tile (registers and / or LDS); returns after its last barrier ----
     {
       const auto karg = __builtin_amdgcn_kernarg_segment_ptr();
       const unsigned baseh = __builtin_amdgcn_readfirstlane((unsigned)(cur >> LOW));
       if constexpr (NBLK == BLOCK) {
         asm volatile(QS_ENGINE_ASM_FULL
-                     :
+                     : "+{v[4:7]}"(x[0]), "+{v[8:11]}"(x[1]), "+{v[12:15]}"(x[2]), "+{v[16:19]}"(x[3]),
+                       "+{v[20:23]}"(x[4]), "+{v[24:27]}"(x[5]), "+{v[28:31]}"(x[6]), "+{v[32:35]}"(x[7])
                      : [tid] "v"(tid), [karg] "s"(karg), [baseh] "s"(baseh), [first] "i"(kTileStreamOff)
                      : QS_ENGINE_CLOBBERS);
       } else {
         asm volatile(QS_ENGINE_ASM_PARTIAL
-                     :
+                     : "+{v[4:7]}"(x[0]), "+{v[8:11]}"(x[1]), "+{v[12:15]}"(x[2]), "+{v[16:19]}"(x[3]),
+                       "+{v[20:23]}"(x[4]), "+{v[24:27]}"(x[5]), "+{v[28:31]}"(x[6]), "+{v[32:35]}"(x[7])
                      : [tid] "v"(tid), [karg] "s"(karg), [baseh] "s"(baseh), [first] "i"(kTileStreamOff), [nblk] "s"(NBLK)
                      : QS_ENGINE_CLOBBERS);
       }
@@ -218,14 +258,19 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
 #ifdef QSIM_PROBES
     if (it == 0) t_engine = __builtin_readcyclecounter();
 #endif
-    {
-      double2 w[PER];
+    if (dout) {                                       // (host: only full tiles, PER == 8)
 #pragma unroll
-      for (int j = 0; j < PER; ++j) w[j] = lds[slot0 + BLOCK * j];
+      for (int j = 0; j < PER; ++j) store(element(cur, j, tout, rout), x[j < 8 ? j : 0]);
+    } else {
+      amp_t w[PER];
 #pragma unroll
-      for (int j = 0; j < PER; ++j) st_amp<NT>(element(cur, j), w[j]);
+      for (int j = 0; j < PER; ++j) w[j] = tile[slot0 + BLOCK * j];
+#pragma unroll
+      for (int j = 0; j < PER; ++j) store(element(cur, j, tout, rout), w[j]);
     }
-    if (it + 1 < TPW) __syncthreads();                // every wave has read its part of the finished tile
+    // the next tile's first LDS write (by the kernel or by the engine's first group change) must not overtake a
+    // wave still reading this tile's last group / result
+    if (it + 1 < TPW) __syncthreads();
   }
 #ifdef QSIM_PROBES
   if (stamps && tid == 0 && (blockIdx.x & 63) == 0) {
@@ -264,9 +309,29 @@ static int serialize_pass(const std::vector<TileGroup>& groups, TileArgs* a) {
   auto put32 = [&](int at, uint32_t v) { std::memcpy(base + at, &v, 4); };
   auto room = [&](int bytes) { return off + bytes + kEndRecordBytes + kTileStreamSlack <= kTileArgBytes; };   // (the SCALE record is inside kTileRecordBudget's reserve)
   bool first = true;
+  if (groups.empty()) return fail(QSIM_ERR_INVALID, "internal: a pass needs at least one register group");
+  // Global <-> register layouts (TileArgs::lay_in / lay_out).  A full tile whose first (last) register group lies
+  // above the line bits is loaded (stored) in that group's layout, skipping one LDS round trip + barrier each;
+  // tuning().tile_direct = 0 keeps everything through LDS.
+  const int nh = a->T - kTileLow;
+  const bool full = a->T == kTileBitsMax && kTileBitsMax - kTileLow == kTileThreadBits;   // 8 amplitudes per thread, 5 + 3 high bits
+  auto layout = [&](const TileGroup& g, uint8_t* lay) -> bool {
+    const bool direct = full && tuning().tile_direct && g.s[0] >= kTileLow;
+    if (!direct) {
+      for (int i = 0; i < nh; ++i) lay[i] = a->h[i];
+      return false;
+    }
+    int nt = 0;
+    for (int b = kTileLow; b < a->T; ++b)
+      if (b != g.s[0] && b != g.s[1] && b != g.s[2]) lay[nt++] = a->h[b - kTileLow];
+    for (int i = 0; i < 3; ++i) lay[nt + i] = a->h[g.s[i] - kTileLow];
+    return true;
+  };
+  const bool din = layout(groups.front(), a->lay_in), dout = layout(groups.back(), a->lay_out);
+  a->order = (uint8_t)((a->order & kTileOrderMask) | (din ? kTileDirectIn : 0) | (dout ? kTileDirectOut : 0));
   for (const TileGroup& g : groups) {
     if (!room(kGroupRecordBytes)) return fail(QSIM_ERR_INVALID, "internal: pass record stream overflow");
-    put32(off + 0, 4u * (first ? OPC_GROUP_FIRST : OPC_GROUP));
+    put32(off + 0, 4u * (first ? (din ? OPC_GROUP_DIRECT : OPC_GROUP_FIRST) : OPC_GROUP));
     put32(off + 4, (uint32_t)(off + kGroupRecordBytes));
     for (int i = 0; i < 3; ++i) put32(off + 8 + 4 * i, ~0u << g.s[i]);
     for (int r = 1; r < 8; ++r) {
@@ -277,7 +342,11 @@ static int serialize_pass(const std::vector<TileGroup>& groups, TileArgs* a) {
     off += kGroupRecordBytes;
     ++nrec;
     first = false;
-    for (const TileDesc& d : g.gates) {
+    for (TileDesc d : g.gates) {
+      // no write-back after the last group of a direct-out pass: a sunk swap (OPC_ASWAP1, which acts by swapping the
+      // write-back addresses) is applied in place instead -- it commutes with everything after it in its group
+      if (dout && &g == &groups.back() && d.opcode >= OPC_ASWAP1 && d.opcode < OPC_ASWAP1 + 9)
+        d.opcode = (uint8_t)(OPC_SWAP1 + (d.opcode - OPC_ASWAP1));
       const int bytes = desc_bytes(d);
       if (!room(bytes)) return fail(QSIM_ERR_INVALID, "internal: pass record stream overflow");
       if ((d.outer_mask & ((1ull << kTileLow) - 1)) || (d.outer_mask >> kTileLow) > 0xFFFFFFFFull)
@@ -301,8 +370,7 @@ static int serialize_pass(const std::vector<TileGroup>& groups, TileArgs* a) {
       ++nrec;
     }
   }
-  if (first) return fail(QSIM_ERR_INVALID, "internal: a pass needs at least one register group");
-  put32(off + 0, 4u * OPC_END);
+  put32(off + 0, 4u * (dout ? OPC_END_DIRECT : OPC_END));
   put32(off + 4, (uint32_t)off);
   ++nrec;
   a->nrec = nrec;

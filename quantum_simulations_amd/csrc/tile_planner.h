@@ -106,7 +106,7 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   if (ntiles > 0xFFFFFFFFull) return fail(QSIM_ERR_INVALID, "internal: too many tiles");
   TileArgs args = a;
   args.ntiles = (uint32_t)ntiles;
-  args.order = (uint8_t)tile_order_for(a, T);
+  args.order = (uint8_t)((a.order & ~kTileOrderMask) | (tile_order_for(a, T) & kTileOrderMask));
 #ifdef QSIM_PROBES
   {   // in-kernel stamps: QSIM_DEBUG_STAMPS=<file> dumps entry / loaded / engine / stored cycle stamps of every 64th workgroup
     static unsigned long long* dbuf = nullptr;
@@ -120,9 +120,10 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
 #ifndef QSIM_TILES_PER_WG
 #define QSIM_TILES_PER_WG 2
 #endif
-  // thread part of an element offset: tile high bits h[0 .. min(5, NH)): 32-bit addressing when all are < 28
+  // thread part of an element offset: the first min(5, NH) bits of the load / store layouts: 32-bit addressing when
+  // all are < 28
   bool wide = false;
-  for (int i = 0; i < kTileThreadBits - kTileLow && i < T - kTileLow; ++i) wide = wide || a.h[i] >= 28;
+  for (int i = 0; i < kTileThreadBits - kTileLow && i < T - kTileLow; ++i) wide = wide || a.lay_in[i] >= 28 || a.lay_out[i] >= 28;
   ProfileScope prof(6, alg_bytes, stream, 32.0 * (double)amps(c));
   bool nt = c->span_bytes > tuning().mall_bytes;       // cache policy by state size (gate_plan.h)
   if (tuning().force_nt >= 0) nt = tuning().force_nt != 0;

@@ -31,7 +31,10 @@ def test_engine_text(partial):
     i = lines.index("s_getpc_b64 s[20:21]")
     assert lines[i + 1].startswith("s_branch ") and all(ln.startswith("s_branch ") for ln in lines[i + 2:i + 2 + 2 * gen.NENT])
     assert not lines[i + 2 + 2 * gen.NENT].startswith("s_branch ")
+    # x0..x7 (v4..v35) are in/out operands of the asm statement (pinned registers), everything else it touches is a clobber
     clobber_v = {int(x) for x in re.findall(r'"v(\d+)"', gen.clobbers())}
+    assert not clobber_v & set(range(4, 36)), "an operand register listed as a clobber"
+    clobber_v |= set(range(4, 36))
     clobber_s = {int(x) for x in re.findall(r'"s(\d+)"', gen.clobbers())}
     for ln in lines:
         if ln.endswith(":"):

@@ -16,13 +16,15 @@ from quantum_simulations_amd import _lib
 from quantum_simulations_amd.kernel.device import pack_ops
 
 IMAGE_BYTES = 4096
-STREAM_OFF = 32                    # byte offset of the first record (csrc/tile_kernel.h)
+STREAM_OFF = 48                    # byte offset of the first record (csrc/tile_kernel.h)
 OPC = dict(DENSE1=1, SWAP1=10, ANTI1=19, PHASE=28, DENSE2=36, REAL1=45, YLIKE1=54, PHASE_NEG=63,
            PHASE_I=71, PHASE_NI=79, DIAGR=87, PRED_OUTER=91, PRED_LANE=92, GROUP=93, GROUP_FIRST=94, END=95,
-           HAD1=96, SCALE=105, ASWAP1=106)
+           HAD1=96, SCALE=105, ASWAP1=106, GROUP_DIRECT=115, END_DIRECT=116)
+DIRECT_IN, DIRECT_OUT = 0x10, 0x20     # TileArgs::order flags
 _FAMILIES = ("DENSE1", "SWAP1", "ANTI1", "PHASE", "DENSE2", "REAL1", "YLIKE1", "PHASE_NEG", "PHASE_I", "PHASE_NI", "DIAGR",
              "HAD1", "SCALE", "ASWAP1")
 _IMAGE = np.dtype([("amp", "<u8"), ("nrec", "<i4"), ("T", "<i4"), ("h", "u1", (11,)), ("order", "u1"), ("ntiles", "<u4"),
+                   ("lay_in", "u1", (8,)), ("lay_out", "u1", (8,)),
                    ("stream", "u1", (IMAGE_BYTES - STREAM_OFF,))])
 assert _IMAGE.itemsize == IMAGE_BYTES
 
@@ -32,26 +34,44 @@ def lds_slot(t: int) -> int:
 
 
 def records(img):
-    """Walk the record stream of a pass image the way the gate engine does: yields
-    ("group", [s0, s1, s2]) and ("gate", opcode, blk_mask, outer_mask, doubles_at(k), size) tuples."""
+    """Walk the record stream of a pass image the way the gate engine does (and check the load / store layouts
+    of the header against the first / last register group): yields ("group", [s0, s1, s2]) and ("gate", opcode, blk_mask, outer_mask, doubles_at(k), size) tuples."""
     raw = bytes(img.tobytes())
     assert len(raw) == IMAGE_BYTES
     off = STREAM_OFF
     seen_group = False
     count = 0
+    groups = []
+    T, h = int(img["T"]), [int(x) for x in img["h"]]
+    din, dout = bool(int(img["order"]) & DIRECT_IN), bool(int(img["order"]) & DIRECT_OUT)
+
+    def check_layout(lay, direct, s):
+        """lay[0..4] thread bits, lay[5..7] register bits of the kernel's global accesses (absolute index bits)"""
+        lay = [int(x) for x in lay][:T - 3]
+        if not direct:
+            assert lay == h[:T - 3], (lay, h)          # through LDS: element tid + 256 j of the tile
+            return
+        assert T == 11 and s[0] >= 3, "direct layout needs a full tile and a group above the line bits"
+        assert lay[5:] == [h[b - 3] for b in s], (lay, s)
+        assert lay[:5] == [h[b - 3] for b in range(3, T) if b not in s], (lay, s)
+
     while True:
         assert off % 16 == 0 and off + 64 <= IMAGE_BYTES, f"record at {off}: the 64-byte fetch leaves the block"
         d = np.frombuffer(raw, dtype="<u4", count=16, offset=off)
         assert d[0] % 4 == 0
         entry, nxt = int(d[0]) // 4, int(d[1])
         count += 1
-        if entry == OPC["END"]:
+        if entry in (OPC["END"], OPC["END_DIRECT"]):
             assert nxt == off and seen_group
             assert count == int(img["nrec"]), (count, int(img["nrec"]))
+            assert (entry == OPC["END_DIRECT"]) == dout
+            check_layout(img["lay_in"], din, groups[0])
+            check_layout(img["lay_out"], dout, groups[-1])
             return
         assert off < nxt <= IMAGE_BYTES - 64 and nxt % 16 == 0, (off, nxt)
-        if entry in (OPC["GROUP"], OPC["GROUP_FIRST"]):
-            assert (entry == OPC["GROUP_FIRST"]) == (not seen_group)
+        if entry in (OPC["GROUP"], OPC["GROUP_FIRST"], OPC["GROUP_DIRECT"]):
+            assert (entry != OPC["GROUP"]) == (not seen_group)
+            assert (entry == OPC["GROUP_DIRECT"]) == (din and not seen_group)
             seen_group = True
             assert nxt == off + 48
             s = []
@@ -63,6 +83,7 @@ def records(img):
             for r in range(1, 8):
                 t = sum(1 << s[i] for i in range(3) if (r >> i) & 1)
                 assert int(d[4 + r]) == lds_slot(t) << 4, "LDS XOR constant"
+            groups.append(s)
             yield ("group", s)
         else:
             assert seen_group, "gate before the first group"
@@ -237,6 +258,9 @@ def run_pass(psi: np.ndarray, img) -> int:
         else:
             raise AssertionError(f"unknown opcode {op}")
         run += 1
+    # a direct-out pass stores the last group's registers straight to global memory: there is no write-back through
+    # LDS addresses for a sunk swap to act in
+    assert not (sunk and int(img["order"]) & DIRECT_OUT), "OPC_ASWAP1 in the last group of a direct-out pass"
     write_back()
     return run
 
