@@ -524,6 +524,9 @@ def engine(partial: bool) -> list[str]:
     # ---- END_DIRECT: the last group is the layout the kernel stores in; the result stays in x0..x7 ----
     a.label("end_direct")
     a("s_mov_b64 exec, -1")
+    # the look-ahead fetch of the record "after" END is still in flight: it must land before the statement
+    # ends, or it overwrites whatever the compiler puts into the (clobbered, hence free) bank registers next
+    a("s_waitcnt lgkmcnt(0)")
     return a.lines
 
 

@@ -290,6 +290,7 @@ struct TileDesc {          // one gate of a register group, before serialisation
 };
 struct TileGroup {
   int s[3];                // ascending tile bits of the register group
+  u64 qmask = 0;           // every qubit its gates touch (planner bookkeeping: groups on disjoint qubits commute)
   std::vector<TileDesc> gates;
 };
 

@@ -211,7 +211,8 @@ static OpShape op_shape(const FusedOp& o) {
 // collect their descriptors.  Ops that do not fit the record budget stay un-emitted (they and
 // everything that depends on them wait for the next launch).
 static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_t>& members,
-                        const std::vector<int>& high, int T, std::vector<TileGroup>* out, std::vector<char>* emitted) {
+                        const std::vector<int>& high, int T, std::vector<TileGroup>* out, std::vector<char>* emitted,
+                        bool last_search = false, int direct_worth = 2) {
   double pass_scale = 1.0;            // product of the factors of the pass's unscaled Hadamard butterflies (OPC_HAD1)
   const int low = kTileLow;
   auto tile_pos = [&](int b) -> int {
@@ -225,70 +226,18 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
   int used = 0;                       // bytes of the records written so far
   const bool merge_on = tuning().tile_merge_diag != 0;
   auto run_bytes = [](unsigned touched) { const int n = __builtin_popcount(touched); return desc_bytes(n == 1 ? 2 : (n == 2 ? 6 : 14)); };
-  while (left) {
-    // Which three tile bits does the group own?  First come (an op that still fits claims the bits it needs)
-    // was the only rule up to r02a; now every triple of the pending ops' target bits is also tried and the one
-    // that lets the group hold the most ops wins (ties: first come).  A group change is an LDS round trip of the
-    // tile plus a barrier (~4 % of a tile's time each): 102 -> 86 groups on the 18 passes of the bench circuit.
-    // Estimate of the record budget: a phase gate that may be merged with others (OPC_DIAGR) is counted as a
-    // bare header; the exact budget is enforced when the group is written out (a group that overflows is cut
-    // there, the rest waits for the next pass).
-    struct Pending { size_t mi; u64 qm; int pos[2]; int npos; int bytes; };
-    std::vector<Pending> pend;
-    pend.reserve(left);
-    unsigned cand_mask = 0;           // tile positions that pending ops target
-    for (size_t mi = 0; mi < members.size(); ++mi) {
-      if (done[mi]) continue;
-      const FusedOp& o = ops[members[mi]];
-      const OpShape shape = op_shape(o);
-      Pending pd;
-      pd.mi = mi;
-      pd.qm = op_qmask(o);
-      pd.npos = o.ntargets;
-      for (int t = 0; t < o.ntargets; ++t) { pd.pos[t] = tile_pos(o.target[t]); cand_mask |= 1u << pd.pos[t]; }
-      pd.bytes = (merge_on && shape.family == OPC_PHASE) ? 16 : desc_bytes(shape.nd);
-      pend.push_back(pd);
-    }
-    // ops a group owning the tile bits `own` (mask) would hold, in list order, within the record budget;
-    // own == 0: first come (bits are claimed as ops need them)
-    auto select = [&](unsigned own, std::vector<size_t>* grp_out, unsigned* claimed_out) -> int {
-      const bool first_come = own == 0;
-      u64 blocked = 0;
-      int est = used + kGroupRecordBytes, count = 0;
-      unsigned claimed = own;
-      for (const Pending& pd : pend) {
-        bool ok = !(blocked & pd.qm);
-        unsigned need = 0;
-        for (int t = 0; t < pd.npos; ++t) need |= 1u << pd.pos[t];
-        if (ok && first_come && __builtin_popcount(claimed | need) > kGroupBits) ok = false;
-        if (ok && !first_come && (need & ~own)) ok = false;
-        if (ok && est + pd.bytes > kTileRecordBudget) ok = false;
-        if (!ok) { blocked |= pd.qm; continue; }
-        claimed |= need;
-        est += pd.bytes;
-        ++count;
-        if (grp_out) grp_out->push_back(pd.mi);
-      }
-      if (claimed_out) *claimed_out = first_come ? claimed : own;
-      return count;
-    };
-    unsigned best_own = 0;
-    int best_count = select(0, nullptr, nullptr);
-    if (tuning().tile_group_search && __builtin_popcount(cand_mask) > kGroupBits) {
-      for (unsigned a = cand_mask; a; a &= a - 1)
-        for (unsigned b = a & (a - 1); b; b &= b - 1)
-          for (unsigned c = b & (b - 1); c; c &= c - 1) {
-            const unsigned own = (a & -a) | (b & -b) | (c & -c);
-            const int count = select(own, nullptr, nullptr);
-            if (count > best_count) { best_count = count; best_own = own; }
-          }
-    }
-    std::vector<size_t> grp;          // indices into members
-    unsigned claimed = 0;
-    select(best_own, &grp, &claimed);
+  const unsigned line_bits = (1u << low) - 1;
+  const bool direct_ends = tuning().tile_direct && T == kTileBitsMax;   // (serialize_pass: full tiles only)
+  // The LAST group of a full tile is free of its LDS write-back when it lies above the line bits (the kernel stores
+  // the tile in that layout, OPC_END_DIRECT).  Chosen first, from the END of the list: the triple of bits above the
+  // line bits that holds the most TERMINAL ops (ops that no op outside the set follows on any of their qubits);
+  // those ops are set aside, the groups in front of them are built as before, and they are written last.
+  bool cut = false;
+  // Write one register group: the ops `grp` (indices into members, list order) on the tile bits `claimed`.
+  // Returns true when the record budget ended inside the group.
+  auto emit_group = [&](const std::vector<size_t>& grp, unsigned claimed) -> bool {
     std::vector<int> S;               // tile bits of this group
     for (unsigned m = claimed; m; m &= m - 1) S.push_back(__builtin_ctz(m));
-    if (grp.empty()) break;           // record budget exhausted: the rest waits for the next launch
     // pad the group with the highest unused tile bits (high bits keep LDS accesses contiguous)
     for (int b = T - 1; (int)S.size() < kGroupBits && b >= 0; --b)
       if (std::find(S.begin(), S.end(), b) == S.end()) S.push_back(b);
@@ -299,6 +248,7 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
     };
     TileGroup tg;
     for (int j = 0; j < 3; ++j) tg.s[j] = S[j];
+    tg.qmask = 0;
     used += kGroupRecordBytes;
     auto emit = [&](TileDesc d) {
       used += desc_bytes(d);
@@ -311,7 +261,6 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
     // end of the group.  One record instead of up to three: the gate loop is instruction-issue bound.
     struct Acc { uint16_t blk; u64 outer; double2 phi[3]; unsigned touched; };
     std::vector<Acc> open;
-    bool cut = false;
     auto cmul2 = [](double2 f, double2 m) { return make_double2(f.x * m.x - f.y * m.y, f.x * m.y + f.y * m.x); };
     auto flush = [&](size_t i) {
       const Acc acc = open[i];
@@ -389,6 +338,7 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
       done[mi] = 1;
       (*emitted)[mi] = 1;
       --left;
+      tg.qmask |= op_qmask(o);
       auto put = [&](int at, double2 v) { d.m[2 * at] = v.x; d.m[2 * at + 1] = v.y; };
       if (o.kind == TG_PHASE) {
         for (int t = 0; t < o.nbits; ++t) require_one(o.bits[t]);
@@ -441,7 +391,145 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
     while (!open.empty()) flush(0);
     if (!tg.gates.empty()) out->push_back(tg);
     else used -= kGroupRecordBytes;
-    if (cut) break;                   // record budget exhausted inside the group
+    return cut;
+  };
+  std::vector<char> reserved(members.size(), 0);
+  unsigned last_own = 0;
+  int reserve_bytes = 0;
+  size_t n_reserved = 0;
+  if (direct_ends && last_search && members.size() > 1) {
+    struct Tail { u64 qm; unsigned need; int bytes; };
+    std::vector<Tail> tail(members.size());
+    unsigned cand = 0;
+    for (size_t mi = 0; mi < members.size(); ++mi) {
+      const FusedOp& o = ops[members[mi]];
+      unsigned need = 0;
+      for (int t = 0; t < o.ntargets; ++t) need |= 1u << tile_pos(o.target[t]);
+      tail[mi] = Tail{op_qmask(o), need, o.kind == TG_PHASE ? 48 : desc_bytes(op_shape(o).nd)};
+      cand |= need & ~line_bits;
+    }
+    auto terminal = [&](unsigned own, std::vector<char>* mark) -> int {
+      u64 blocked = 0;
+      int count = 0, bytes = kGroupRecordBytes;
+      for (size_t mi = members.size(); mi-- > 0;) {
+        const Tail& t = tail[mi];
+        if ((blocked & t.qm) || (t.need & ~own) || bytes + t.bytes > kTileRecordBudget / 2) { blocked |= t.qm; continue; }
+        bytes += t.bytes;
+        ++count;
+        if (mark) (*mark)[mi] = 1;
+      }
+      if (mark) reserve_bytes = bytes;
+      return count;
+    };
+    int best = 0;
+    while (__builtin_popcount(cand) < kGroupBits)          // fewer than three target bits above the line bits: pad
+      for (int b = T - 1; b >= low; --b) if (!(cand & (1u << b))) { cand |= 1u << b; break; }
+    for (unsigned a = cand; a; a &= a - 1)
+      for (unsigned b = a & (a - 1); b; b &= b - 1)
+        for (unsigned c = b & (b - 1); c; c &= c - 1) {
+          const unsigned own = (a & -a) | (b & -b) | (c & -c);
+          const int count = terminal(own, nullptr);
+          if (count > best) { best = count; last_own = own; }
+        }
+    if (best > 0 && (size_t)best < members.size()) {
+      n_reserved = (size_t)terminal(last_own, &reserved);
+      used = reserve_bytes;
+    } else {
+      last_own = 0;
+    }
+  }
+  while (left > n_reserved) {
+    // Which three tile bits does the group own?  First come (an op that still fits claims the bits it needs)
+    // was the only rule up to r02a; now every triple of the pending ops' target bits is also tried and the one
+    // that lets the group hold the most ops wins (ties: first come).  A group change is an LDS round trip of the
+    // tile plus a barrier (~4 % of a tile's time each): 102 -> 86 groups on the 18 passes of the bench circuit.
+    // Estimate of the record budget: a phase gate that may be merged with others (OPC_DIAGR) is counted as a
+    // bare header; the exact budget is enforced when the group is written out (a group that overflows is cut
+    // there, the rest waits for the next pass).
+    struct Pending { size_t mi; u64 qm; int pos[2]; int npos; int bytes; };
+    std::vector<Pending> pend;
+    pend.reserve(left);
+    unsigned cand_mask = 0;           // tile positions that pending ops target
+    for (size_t mi = 0; mi < members.size(); ++mi) {
+      if (done[mi] || reserved[mi]) continue;
+      const FusedOp& o = ops[members[mi]];
+      const OpShape shape = op_shape(o);
+      Pending pd;
+      pd.mi = mi;
+      pd.qm = op_qmask(o);
+      pd.npos = o.ntargets;
+      for (int t = 0; t < o.ntargets; ++t) { pd.pos[t] = tile_pos(o.target[t]); cand_mask |= 1u << pd.pos[t]; }
+      pd.bytes = (merge_on && shape.family == OPC_PHASE) ? 16 : desc_bytes(shape.nd);
+      pend.push_back(pd);
+    }
+    // ops a group owning the tile bits `own` (mask) would hold, in list order, within the record budget;
+    // own == 0: first come (bits are claimed as ops need them)
+    auto select = [&](unsigned own, std::vector<size_t>* grp_out, unsigned* claimed_out) -> int {
+      const bool first_come = own == 0;
+      u64 blocked = 0;
+      int est = used + kGroupRecordBytes, count = 0;
+      unsigned claimed = own;
+      for (const Pending& pd : pend) {
+        bool ok = !(blocked & pd.qm);
+        unsigned need = 0;
+        for (int t = 0; t < pd.npos; ++t) need |= 1u << pd.pos[t];
+        if (ok && first_come && __builtin_popcount(claimed | need) > kGroupBits) ok = false;
+        if (ok && !first_come && (need & ~own)) ok = false;
+        if (ok && est + pd.bytes > kTileRecordBudget) ok = false;
+        if (!ok) { blocked |= pd.qm; continue; }
+        claimed |= need;
+        est += pd.bytes;
+        ++count;
+        if (grp_out) grp_out->push_back(pd.mi);
+      }
+      if (claimed_out) *claimed_out = first_come ? claimed : own;
+      return count;
+    };
+    unsigned best_own = 0;
+    unsigned fc_claimed = 0;
+    int best_count = select(0, nullptr, &fc_claimed);
+    // The FIRST group of a full tile is free of its LDS read when it lies above the line bits (the kernel loads the
+    // tile in that layout, OPC_GROUP_DIRECT): such a triple wins unless another one holds `direct_worth` more ops.
+    const bool want_direct = out->empty() && direct_ends;
+    auto score = [&](int count, unsigned own_bits) { return count * 2 + ((want_direct && direct_worth && !(own_bits & line_bits)) ? 2 * direct_worth - 1 : 0); };
+    int best_score = score(best_count, fc_claimed);
+    if (tuning().tile_group_search && __builtin_popcount(cand_mask) > kGroupBits) {
+      for (unsigned a = cand_mask; a; a &= a - 1)
+        for (unsigned b = a & (a - 1); b; b &= b - 1)
+          for (unsigned c = b & (b - 1); c; c &= c - 1) {
+            const unsigned own = (a & -a) | (b & -b) | (c & -c);
+            const int count = select(own, nullptr, nullptr);
+            if (score(count, own) > best_score) { best_score = score(count, own); best_count = count; best_own = own; }
+          }
+    }
+    std::vector<size_t> grp;          // indices into members
+    unsigned claimed = 0;
+    select(best_own, &grp, &claimed);
+    if (grp.empty()) break;           // record budget exhausted: the rest waits for the next launch
+    if (emit_group(grp, claimed)) break;   // record budget exhausted inside the group
+  }
+  if (n_reserved) {
+    // the group set aside for the end: an op of it waits for the next launch with everything un-emitted that it follows
+    used -= reserve_bytes;
+    std::vector<size_t> grp;
+    u64 blocked = 0;
+    for (size_t mi = 0; mi < members.size(); ++mi) {
+      if (done[mi]) continue;
+      const u64 qm = op_qmask(ops[members[mi]]);
+      if (!reserved[mi] || (blocked & qm)) { blocked |= qm; continue; }
+      grp.push_back(mi);
+    }
+    if (!grp.empty()) emit_group(grp, last_own);
+  }
+
+  // The LAST group of a full tile is free of its LDS write-back when it lies above the line bits (OPC_END_DIRECT):
+  // a last group that does not is moved in front of its predecessors as long as it shares no qubit with them
+  // (groups on disjoint qubits commute), while that leaves a direct-capable group at the end.
+  if (tuning().tile_direct && T == kTileBitsMax && out->size() > 1 && out->back().s[0] < low) {
+    size_t at = out->size() - 1;
+    while (at > 0 && !((*out)[at].qmask & (*out)[at - 1].qmask)) { std::swap((*out)[at], (*out)[at - 1]); --at; }
+    if (out->back().s[0] < low)       // nothing gained: keep the original order
+      while (at + 1 < out->size()) { std::swap((*out)[at], (*out)[at + 1]); ++at; }
   }
   if (pass_scale != 1.0 && !out->empty()) {   // a global factor commutes with everything: applied once
     // ... for free when the pass has an unconditional dense / real / anti-diagonal 1q gate (every amplitude goes
@@ -611,6 +699,23 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops, int* n_passes, Sin
     std::vector<char> emitted(members.size(), 0);
     std::vector<TileGroup> groups;
     emit_groups(ops, members, high, T, &groups, &emitted);
+    if (lookahead && tune.tile_direct && tune.tile_last_search && T == kTileBitsMax) {
+      // second plan of the same pass with the last group chosen from the end (see emit_groups); LDS round trips of a
+      // tile = group changes + a first group that is not loaded in place + a last group that is not stored in place
+      auto trips = [&](const std::vector<TileGroup>& g) {
+        return g.empty() ? 1 << 20 : (int)g.size() + (g.front().s[0] < kTileLow) + (g.back().s[0] < kTileLow);
+      };
+      auto count = [](const std::vector<char>& e) { size_t c = 0; for (char x : e) c += x != 0; return c; };
+      std::vector<char> emitted2(members.size(), 0);
+      std::vector<TileGroup> groups2;
+      emit_groups(ops, members, high, T, &groups2, &emitted2, true);
+      if (count(emitted2) > count(emitted) || (count(emitted2) == count(emitted) && trips(groups2) < trips(groups))) {
+        groups.swap(groups2);
+        emitted.swap(emitted2);
+      }
+      // (four more variants -- the first group's preference for a direct triple off / stronger, each with and without the
+      // last-group search -- save one more round trip in 84 on the bench circuit: not worth three times the planning)
+    }
     size_t n_emitted = 0;
     double alg_bytes = 0;   // dense 32N, diagonal / controlled / SWAP 16N, CZ/CR 8N
     for (size_t mi = 0; mi < members.size(); ++mi)

@@ -71,3 +71,16 @@ def test_every_case_ends_with_a_dispatch_and_the_committed_header_is_current():
     assert gen.c_string(lines).replace("\n", " \\\n") in header, "tile_engine_gen.h is stale: run make in csrc/"
     for name, value in gen.OPC.items():
         assert f"#define QS_ENT_{name} {value}\n" in header
+
+
+def test_no_scalar_load_in_flight_when_the_statement_ends():
+    """Every record is fetched one ahead, so a fetch is in flight at END; the compiler treats the bank registers as
+    free after the statement -- a fetch landing later would overwrite its values (seen as a rare wrong result with
+    OPC_END_DIRECT before the wait was there).  Both exits must wait for lgkmcnt(0) after their label."""
+    for partial in (False, True):
+        lines = gen.engine(partial)
+        for label in (".Lqs_end_%=:", ".Lqs_end_direct_%=:"):
+            at = lines.index(label)
+            nxt = next((i for i in range(at + 1, len(lines)) if lines[i].endswith(":")), len(lines))
+            assert "s_waitcnt lgkmcnt(0)" in lines[at:nxt], label
+        assert lines[-1] == "s_waitcnt lgkmcnt(0)" or "s_barrier" in lines[-2:], lines[-3:]

@@ -149,6 +149,10 @@ def _worker(rank, world, port, errors, results):
             got = eng.state_vector()                                                # gathered, logical order
             if rank == 0:
                 err = float(np.max(np.abs(got - want)))
+                if err > 1e-10:        # where: index range and the index bits the wrong amplitudes share / differ in
+                    bad = np.flatnonzero(np.abs(got - want) > 1e-10)
+                    print(f"[staging={staging}] {bad.size} wrong amplitudes, first {bad[:8].tolist()}, last {int(bad[-1])}, "
+                          f"AND {int(np.bitwise_and.reduce(bad)):#x} OR {int(np.bitwise_or.reduce(bad)):#x}", file=sys.stderr, flush=True)
                 results.put((staging, err, norm2, stats["exchanges"], stats["bytes_sent_per_rank"]))
             del got
             eng.backend.close()

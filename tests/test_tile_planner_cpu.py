@@ -27,6 +27,23 @@ def test_planned_passes_equal_oracle_random_ops(n):
         np.testing.assert_allclose(psi, want, rtol=0, atol=1e-12, err_msg=f"n={n} seed={seed}")
 
 
+def test_direct_layouts_of_full_tiles():
+    """A full tile whose first / last register group lies above the line bits is loaded / stored in that group's
+    layout (TileArgs::lay_in / lay_out, OPC_GROUP_DIRECT / OPC_END_DIRECT); the record walker checks the layouts
+    against the groups, run_pass that no sunk swap is left without a write-back.  Smaller tiles never are."""
+    seen_in = seen_out = total = 0
+    for seed in range(6):
+        for n in (11, 13, 14):
+            for img in ti.plan(n, _random_ops(n, 150, 4000 + 10 * n + seed)):
+                list(ti.records(img))
+                seen_in += bool(int(img["order"]) & ti.DIRECT_IN)
+                seen_out += bool(int(img["order"]) & ti.DIRECT_OUT)
+                total += 1
+    assert seen_in > total // 2 and seen_out > total // 4, (seen_in, seen_out, total)
+    for img in ti.plan(9, _random_ops(9, 100, 77)):
+        assert int(img["T"]) < 11 and not int(img["order"]) & (ti.DIRECT_IN | ti.DIRECT_OUT)
+
+
 def test_phase_runs_are_merged_and_ordered():
     """QFT: the CR(k, a), CR(k, b), CR(k, c) of a register group share one descriptor, and every
     merged run is written out before the next Hadamard on one of its bits."""

@@ -1,0 +1,68 @@
+"""Debug aid: the 26-qubit four-rank run of tests/test_gpu_fullsize.py with every apply_ops call of every rank checked
+against the C oracle on the downloaded shard; the first mismatch is dumped (ops, wrong-index pattern) to gpurun_out/."""
+import os, sys, pickle, traceback
+import multiprocessing as mp
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+N4 = 26
+
+
+def worker(rank, world, port):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        from oracle import c_oracle
+        from quantum_simulations_amd.circuits import random_clifford_t_circuit
+        from quantum_simulations_amd.runner.distributed import DistributedEngine, HipShardBackend
+        c_oracle.set_threads(4)
+
+        class Checked(HipShardBackend):
+            calls = 0
+
+            def apply_ops(self, ops):
+                before = self.download()
+                r = super().apply_ops(ops)
+                got = self.download()
+                want = before
+                for qs, U in ops:
+                    U = np.ascontiguousarray(U, dtype=complex)
+                    if len(qs) == 1: c_oracle.apply_1q(want, qs[0], U)
+                    else: c_oracle.apply_2q(want, qs[0], qs[1], U)
+                err = float(np.max(np.abs(got - want)))
+                Checked.calls += 1
+                if err > 1e-10:
+                    bad = np.flatnonzero(np.abs(got - want) > 1e-10)
+                    msg = (f"[rank {rank}] call {Checked.calls}: {len(ops)} ops, {r} passes, err {err:.3e}, {bad.size} wrong, first {bad[:6].tolist()} "
+                           f"last {int(bad[-1])} AND {int(np.bitwise_and.reduce(bad)):#x} OR {int(np.bitwise_or.reduce(bad)):#x}")
+                    print(msg, flush=True)
+                    os.makedirs("gpurun_out", exist_ok=True)
+                    path = f"gpurun_out/badcall_rank{rank}_{Checked.calls}.pkl"
+                    if not os.path.exists(path) and len([f for f in os.listdir("gpurun_out") if f.startswith("badcall")]) < 4:
+                        with open(path, "wb") as f:
+                            pickle.dump({"ops": [(list(q), np.asarray(U)) for q, U in ops], "bad": bad[:100000], "msg": msg}, f)
+                    # repair so that later calls are judged on their own
+                    self.chunk("state").upload(want)
+                return r
+
+        cd = random_clifford_t_circuit(N4, depth=60)
+        p = world.bit_length() - 1
+        for staging in (True, False):
+            eng = DistributedEngine(N4, world, rank, backend=Checked(N4 - p, 0), staging=staging)
+            eng.init_zero_state()
+            eng.execute(eng.plan(cd))
+            print(f"[rank {rank}] staging={staging}: {Checked.calls} apply_ops calls checked", flush=True)
+            eng.backend.close()
+        eng.close()
+    except Exception:
+        traceback.print_exc()
+        raise
+
+
+if __name__ == "__main__":
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=worker, args=(r, 4, port)) for r in range(4)]
+    for p in procs: p.start()
+    for p in procs: p.join(800)
+    sys.exit(max(p.exitcode or 0 for p in procs))
