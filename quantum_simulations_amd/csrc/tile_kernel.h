@@ -140,7 +140,10 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
   constexpr int PER = N / BLOCK;                      // tile elements per thread
   constexpr int NBLK = N >> kGroupBits;               // register blocks per tile (<= BLOCK)
   static_assert(N >= BLOCK && NBLK <= BLOCK, "one register block per thread, at least one element per thread");
-  __shared__ double2 lds[N];                          // the only LDS object: the engine addresses it from 0
+#ifndef QSIM_LDS_PAD_ELEMS
+#define QSIM_LDS_PAD_ELEMS 0                          // (probe: extra LDS per workgroup lowers the residency)
+#endif
+  __shared__ double2 lds[N + QSIM_LDS_PAD_ELEMS];     // the only LDS object: the engine addresses it from 0
 #ifdef QSIM_PROBES
   // in-kernel stamps (probe build): entry / tile loaded / engine done / stores issued, per sampled workgroup
   unsigned long long* const stamps = *reinterpret_cast<unsigned long long* const*>(&a.stream[(kTileArgBytes - 8 - kTileStreamOff) / 4]);

@@ -15,6 +15,7 @@ struct FusedOp {
   double2 m[16];
   int nm;              // matrix entries (4, 1 or 16)
   int halvings;        // algorithmic bytes = 32 B x 2^(k - halvings)  
+  double absorbed;     // algorithmic bytes of the gates fused into this one, as a fraction of 32 B x 2^k
 };
 
 static void set_1q_kind(FusedOp* o) {   // o->m holds the 2x2
@@ -32,6 +33,7 @@ static bool classify_op(int nq, const int32_t* q, const double* U, FusedOp* o) {
   o->nbits = 0;
   o->ntargets = 0;
   o->halvings = 0;
+  o->absorbed = 0.0;
   auto C = [&](int i) { return make_double2(U[2 * i], U[2 * i + 1]); };
   if (nq == 1) {
     const bool diag = is_zero(U[2], U[3]) && is_zero(U[4], U[5]);
@@ -175,13 +177,108 @@ static int launch_tile_any(const TileArgs& a, int T, const qsim_chunk* c, hipStr
   return fail(QSIM_ERR_INVALID, "internal: tile size %d", T);
 }
 
-constexpr int kTileMinChunk = 8;   // smaller chunks run gate by gate
-
 static inline u64 op_qmask(const FusedOp& o) {
   u64 m = 1ull << o.qubits[0];
   if (o.nq == 2) m |= 1ull << o.qubits[1];
   return m;
 }
+
+// ---- commutation-aware fusion of one-qubit gates -------------------------------------------------
+// The host planners (circuit/fusion.py, the reference's fuse_1q_ops) only merge 1q gates that are ADJACENT on their
+// qubit.  Inside the library a 1q gate G on qubit q also moves forward past every op it commutes with -- a
+// controlled gate whose control is q when G is diagonal (Z, S, T, R), a controlled gate whose target is q when G
+// commutes with its 2x2 (X through CNOT targets), a CZ / CR on q when G is diagonal -- and is multiplied into the
+// next 1q gate on q.  Same unitary (rounding differs at 1e-16); on the bench circuit 1 in 5 1q gates disappears
+// this way, among them every X (the costliest 1q record of the engine: 16 v_swap_b32 at half rate).
+static inline double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+static inline double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+static bool op_1q_matrix(const FusedOp& o, double2 g[4]) {   // uncontrolled 1q op -> its 2x2
+  if (o.kind == TG_PHASE && o.nbits == 1) {
+    g[0] = make_double2(1, 0); g[1] = g[2] = make_double2(0, 0); g[3] = o.m[0];
+    return true;
+  }
+  if ((o.kind == TG_DENSE1 || o.kind == TG_ANTI1 || o.kind == TG_SWAP1) && o.control < 0) {
+    for (int i = 0; i < 4; ++i) g[i] = o.m[i];
+    return true;
+  }
+  return false;
+}
+static int op_cost(const FusedOp& o);          // vector instructions per thread of the uncontrolled record (below)
+constexpr int kRecordCost = 8;                 // a record's fetch + dispatch, in the same unit
+static void commute_fuse_1q(std::vector<FusedOp>* ops, bool backward) {
+  // forward: gate i moves later, into the next 1q gate j on its qubit (the product sits at j); backward: that gate j
+  // moves earlier, into i (the product sits at i) -- legal under the same condition, everything between them on the
+  // qubit commuting with the gate that moves... which for the backward form is gate j: its matrix is the one tested.
+  const size_t n = ops->size();
+  std::vector<char> dead(n, 0);
+  constexpr size_t kWindow = 512;              // ops looked at behind a gate (bounds the cost on long lists)
+  auto zero = [](double2 v) { return v.x == 0 && v.y == 0; };
+  auto commutes_with = [&](const double2 g[4], const FusedOp& o, int q) {
+    const bool diag = zero(g[1]) && zero(g[2]);
+    if (o.kind == TG_PHASE) return diag;                                   // CZ / CR
+    if (o.kind == TG_DENSE2) return false;
+    if (o.control == q) return diag;                                       // q controls it
+    if (o.control >= 0 && o.target[0] == q) {                              // q is its target: g v == v g ?
+      const double2* v = o.m;
+      for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 2; ++c) {
+          const double2 gv = cadd(cmul(g[2 * r], v[c]), cmul(g[2 * r + 1], v[2 + c]));
+          const double2 vg = cadd(cmul(v[2 * r], g[c]), cmul(v[2 * r + 1], g[2 + c]));
+          if (gv.x != vg.x || gv.y != vg.y) return false;
+        }
+      return true;
+    }
+    return false;
+  };
+  for (size_t i = 0; i < n; ++i) {
+    double2 g[4];
+    if (dead[i] || !op_1q_matrix((*ops)[i], g)) continue;
+    const int q = (*ops)[i].qubits[0];
+    // the next 1q gate j on q, and whether everything on q in between commutes with the gate that moves
+    size_t j = i + 1;
+    bool g_passes = true, found = false;
+    std::vector<size_t> between;
+    for (; j < n && j <= i + kWindow; ++j) {
+      const FusedOp& o = (*ops)[j];
+      if (dead[j] || !((op_qmask(o) >> q) & 1)) continue;
+      double2 h[4];
+      if (op_1q_matrix(o, h)) { found = true; break; }
+      between.push_back(j);
+      if (!backward && !commutes_with(g, o, q)) { g_passes = false; break; }
+    }
+    if (!found || !g_passes) continue;
+    double2 h[4];
+    op_1q_matrix((*ops)[j], h);
+    if (backward) {
+      bool ok = true;
+      for (size_t b : between) ok = ok && commutes_with(h, (*ops)[b], q);
+      if (!ok) continue;
+    }
+    const double2 f[4] = {cadd(cmul(h[0], g[0]), cmul(h[1], g[2])), cadd(cmul(h[0], g[1]), cmul(h[1], g[3])),
+                          cadd(cmul(h[2], g[0]), cmul(h[3], g[2])), cadd(cmul(h[2], g[1]), cmul(h[3], g[3]))};
+    const double U[8] = {f[0].x, f[0].y, f[1].x, f[1].y, f[2].x, f[2].y, f[3].x, f[3].y};
+    const int32_t qq[2] = {q, -1};
+    auto frac = [](const FusedOp& x) { return x.absorbed + 1.0 / (double)(1ull << (x.kind == TG_PHASE ? x.nbits : x.halvings)); };
+    const size_t keep = backward ? i : j, drop = backward ? j : i;
+    const double moved = (*ops)[keep].absorbed + frac((*ops)[drop]);
+    FusedOp fused;
+    const bool identity = !classify_op(1, qq, U, &fused);
+    // Worth it?  The engine's special cases are cheap (Z 8, H 16, T 16, S 20 vector instructions per thread against 32
+    // for a real 2x2, 40 anti-diagonal, 68 complex): a product that costs more than its factors plus one record's
+    // dispatch is left alone (measured: fusing everything that commutes made the pass 2 % slower at 15 % fewer records).
+    if (!identity && op_cost(fused) > op_cost((*ops)[i]) + op_cost((*ops)[j]) + kRecordCost) continue;
+    if (!identity) { fused.absorbed = moved; (*ops)[keep] = fused; }
+    else dead[keep] = 1;                        // the product is the identity
+    dead[drop] = 1;
+    if (backward && !dead[i]) --i;              // the product may take the next gate in as well
+  }
+  size_t w = 0;
+  for (size_t i = 0; i < n; ++i) if (!dead[i]) (*ops)[w++] = (*ops)[i];
+  ops->resize(w);
+}
+
+constexpr int kTileMinChunk = 8;   // smaller chunks run gate by gate
+
 
 // The case an op gets once its register positions are known depends only on its kind and matrix:
 // family entry and matrix doubles of the record (tile_kernel.h, record stream).
@@ -204,6 +301,18 @@ static OpShape op_shape(const FusedOp& o) {
         return {OPC_HAD1, 0};
       return (sp && o.m[0].y == 0 && o.m[1].y == 0 && o.m[2].y == 0 && o.m[3].y == 0) ? OpShape{OPC_REAL1, 4}
                                                                                         : OpShape{OPC_DENSE1, 8};
+  }
+}
+
+static int op_cost(const FusedOp& o) {
+  switch (op_shape(o).family) {
+    case OPC_PHASE_NEG: return 8;
+    case OPC_PHASE: case OPC_HAD1: return 16;
+    case OPC_PHASE_I: case OPC_PHASE_NI: return 20;
+    case OPC_SWAP1: case OPC_REAL1: return 32;
+    case OPC_ANTI1: case OPC_YLIKE1: return 40;
+    case OPC_DENSE1: return 68;
+    default: return 144;
   }
 }
 
@@ -569,8 +678,12 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
 // `sink(args, T, algorithmic_bytes)` receives every planned pass: the launcher on the device path,
 // a serialiser in qsim_plan_ops (the planner itself never touches the GPU).
 template <class Sink>
-static int plan_fused(int k, const std::vector<FusedOp>& ops, int* n_passes, Sink&& sink) {
+static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, Sink&& sink) {
   const Tuning& tune = tuning();
+  std::vector<FusedOp> ops = ops_in;
+  if (tune.tile_commute_fuse == 1 || tune.tile_commute_fuse == 4) commute_fuse_1q(&ops, false);
+  if (tune.tile_commute_fuse >= 2) commute_fuse_1q(&ops, true);
+  if (tune.tile_commute_fuse == 3) commute_fuse_1q(&ops, false);
   const int T = k < kTileBitsMax ? k : kTileBitsMax;
   const int low = kTileLow;
   const int cap = T - low;                      // tile high-bit capacity
@@ -722,7 +835,7 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops, int* n_passes, Sin
       if (emitted[mi]) {
         const FusedOp& o = ops[members[mi]];
         const int halvings = o.kind == TG_PHASE ? o.nbits : (o.control >= 0 ? 1 : o.halvings);
-        alg_bytes += 32.0 * (double)((1ull << k) >> halvings);
+        alg_bytes += 32.0 * (double)((1ull << k) >> halvings) + 32.0 * (double)(1ull << k) * o.absorbed;
         done[members[mi]] = 1; --remaining; ++n_emitted;
       }
     if (!n_emitted) return fail(QSIM_ERR_INVALID, "internal: fused planner emitted nothing");

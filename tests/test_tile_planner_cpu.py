@@ -63,6 +63,53 @@ def test_phase_runs_are_merged_and_ordered():
                for img in images for rec in ti.records(img))
 
 
+def test_commuting_1q_gates_are_fused():
+    """Library-side fusion of 1q gates across ops they commute with (csrc/tile_planner.h commute_fuse_1q): X through
+    CNOT targets, Z / S / T through controls and CZ / CR; H must NOT pass a CNOT.  Fewer records, same state."""
+    if os.environ.get("QSIM_TILE_COMMUTE_FUSE") != "2":
+        # off by default (measured neutral); the knob is read once per process: run this test alone in a child
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, QSIM_TILE_COMMUTE_FUSE="2", PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", __file__ + "::test_commuting_1q_gates_are_fused"],
+                             cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        return
+    H, X, Z, S, T = (orc.gate_matrix(g, {}) for g in ("H", "X", "Z", "S", "T"))
+    CNOT, CZ = orc.gate_matrix("CNOT", {}), orc.gate_matrix("CZ", {})
+    n = 9
+    for seed in range(3):                         # random circuits under the fusion: same state as the oracle
+        ops = _random_ops(12, 150, 8800 + seed)
+        psi = _rand_state(12, 8900 + seed)
+        want = psi.copy()
+        orc.apply_ops(want, ops)
+        ti.run(psi, ti.plan(12, ops))
+        np.testing.assert_allclose(psi, want, rtol=0, atol=1e-12, err_msg=str(seed))
+
+    def records_of(ops):
+        return sum(1 for img in ti.plan(n, ops) for r in ti.records(img) if r[0] == "gate")
+
+    # (the later gate moves back to the earlier one: that order keeps the pass count of the bench circuit at 18)
+    cases = [
+        ([([4], H), ([1, 4], CNOT), ([4], X)], [([4], X @ H), ([1, 4], CNOT)]),        # X passes the target
+        ([([1], S), ([1, 4], CNOT), ([1], T)], [([1], T @ S), ([1, 4], CNOT)]),        # T passes the control
+        ([([1], Z), ([1, 4], CZ), ([4, 1], CZ), ([1], T)], [([1], T @ Z), ([1, 4], CZ), ([4, 1], CZ)]),
+        ([([4], X), ([1, 4], CNOT), ([4], X)], [([1, 4], CNOT)]),                      # X X = 1 across the target
+        ([([4], H), ([1, 4], CNOT), ([4], H)], None),          # H does not commute with the CNOT on its target
+        ([([1], X), ([1, 4], CNOT), ([1], X)], None),          # X on the CONTROL does not commute either
+        ([([4], X), ([1, 4], CNOT), ([4], H)], None),          # H (the gate that would move) cannot pass the CNOT
+    ]
+    for seed, (ops, fused_by_hand) in enumerate(cases):
+        psi = _rand_state(n, 50 + seed)
+        want = psi.copy()
+        orc.apply_ops(want, ops)
+        ti.run(psi, ti.plan(n, ops))
+        np.testing.assert_allclose(psi, want, rtol=0, atol=1e-13, err_msg=str(seed))
+        if fused_by_hand is not None:
+            assert records_of(ops) == records_of(fused_by_hand) < len(ops), seed
+        else:
+            assert records_of(ops) >= len(ops), seed          # nothing merged (a Hadamard scale record may be added)
+
+
 def test_bench_workload_pass_count():
     """The 28-qubit depth-40 bench circuit plans into 18 passes with the two-deep tile-bit look-ahead
     (19 one deep, 24 with the first-come rule alone); planning needs no device."""
@@ -71,6 +118,8 @@ def test_bench_workload_pass_count():
     from quantum_simulations_amd.circuits import random_1q_cx_circuit
     cd = validate_circuit_dict(random_1q_cx_circuit(28, depth=40))
     total = sum(len(ti.plan(28, p["local_ops"])) for p in batch_levels(levelize(cd), 28))
+    if os.environ.get("QSIM_TILE_COMMUTE_FUSE", "0") != "0":
+        pytest.skip("pass counts are pinned for the default planner")
     assert total == {"0": 24, "1": 19}.get(os.environ.get("QSIM_PLAN_LOOKAHEAD"), 18)
 
 
