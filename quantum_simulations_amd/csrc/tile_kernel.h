@@ -110,9 +110,16 @@ static_assert(offsetof(TileArgs, stream) == kTileStreamOff, "record offsets are 
 // conflicts are not what limits the gate phase).  Linear over GF(2): the engine relies on it.
 __host__ __device__ __forceinline__ unsigned lds_slot(unsigned t) { return t ^ ((t >> 4) & 15u); }
 
-// min waves per SIMD asked of the register allocator: what the LDS footprint admits, capped
-constexpr int tile_waves(int T, int tiles_per_wg = 1) {   // (with a prefetched tile in flight the kernel needs 95 VGPRs: still 5)
-  return (160 * 1024) / ((1 << T) * 16) > 5 ? 5 : (160 * 1024) / ((1 << T) * 16);
+// Waves per SIMD the register allocator may count on = workgroups per CU that the LDS footprint admits (one wave per
+// SIMD each).  gfx950 hands out its 160 KiB of LDS in 1280-byte granules, so the 32 KiB of a 2^11 tile takes 26 of the
+// 128 and FOUR workgroups fit, not five (tools/occupancy_probe.hip, profiles/r02x_occupancy_probe.txt: 5 at <= 32000 B,
+// 4 at 32768 B) -- which leaves 128 VGPRs per wave.  Residency is not what limits the pass: 3 -> 4 workgroups per CU
+// gain 2 % (profiles/r02x_ab_residency.txt).  Tried with the room (profiles/r02z_ab_paired_stores.txt): the first
+// tile's result kept in registers and both tiles of a workgroup stored back to back -- 1.1 % SLOWER (the stores start
+// later); tiles of a workgroup half the state apart instead of adjacent -- 4.7 % slower (adjacent tiles share DRAM pages).
+constexpr int tile_waves(int T, int tiles_per_wg = 1) {
+  const int granules = ((1 << T) * 16 + 1279) / 1280;
+  return 128 / granules > 5 ? 5 : 128 / granules;   // (small tiles: 5 as before, their kernels use < 96 VGPRs anyway)
 }
 
 // TPW tiles per workgroup (1 or 2): with 2, the second tile's global loads are issued BEFORE the gate engine
@@ -151,6 +158,13 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
   unsigned long long t_loaded = 0, t_engine = 0;
 #endif
   const int tid = threadIdx.x;
+#ifdef QSIM_STAGGER
+  // (probe) the workgroups of the first dispatch round start together and stay in phase: offset the four that share a CU
+  if (blockIdx.x < 1024) {
+    const int steps = (blockIdx.x >> 8) & 3;
+    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(QSIM_STAGGER);
+  }
+#endif
   int hs[NH];                                         // the tile's high bits, pinned to scalar registers
 #pragma unroll
   for (int j = 0; j < NH; ++j) hs[j] = __builtin_amdgcn_readfirstlane((int)a.h[j]);
@@ -175,7 +189,11 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
   // Which tile a workgroup takes: TPW consecutive tiles per workgroup; order 0 = consecutive tiles in flight,
   // 1 = hashed, 2 = bit-reversed (probe build only, see tile_order_for).  ntiles is a power of two.
   auto tile_base = [&](unsigned i) -> u64 {
+#ifdef QSIM_TILE_STRIDED
+    unsigned tile = blockIdx.x + i * gridDim.x;       // (probe) the workgroups in flight cover consecutive tiles at every step
+#else
     unsigned tile = blockIdx.x * TPW + i;
+#endif
 #ifdef QSIM_PROBES
     if ((a.order & kTileOrderMask) == 1) tile = (tile * 0x9E3779B1u) & (a.ntiles - 1);
     if ((a.order & kTileOrderMask) == 2) tile = a.ntiles > 1 ? __brev(tile) >> (__clz(a.ntiles) + 1) : 0;

@@ -130,13 +130,15 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   bool nt = c->span_bytes > tuning().mall_bytes;       // cache policy by state size (gate_plan.h)
   if (tuning().force_nt >= 0) nt = tuning().force_nt != 0;
   // Two tiles per workgroup, the second one's loads in flight while the first is computed on
-  // (profiles/r02r_ab_prefetch_before_engine.txt: -3.9 % per pass at 95 VGPRs, still 5 workgroups per CU; 4 or 8
-  // tiles per workgroup lose it again).  Not for the 64-bit-offset form (one VGPR too many: it would spill) and
-  // not for small grids.
+  // (profiles/r02r_ab_prefetch_before_engine.txt: -3.9 % per pass; 4 or 8 tiles per workgroup lose it again,
+  // profiles/r02z_ab_paired_stores.txt).  Also for the 64-bit-offset form (110 VGPRs: the 32 KiB of LDS admit four
+  // workgroups per CU, so 128 are there); not for small grids.
   constexpr int TPW = QSIM_TILES_PER_WG;
-  if (TPW > 1 && !wide && ntiles >= (u64)TPW * 4096) {
+  if (TPW > 1 && ntiles >= (u64)TPW * 4096) {
     const unsigned grid = (unsigned)(ntiles / TPW);
-    if (nt) hipLaunchKernelGGL((k_tile<T, true, false, TPW>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+    if (nt && wide) hipLaunchKernelGGL((k_tile<T, true, true, TPW>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+    else if (nt) hipLaunchKernelGGL((k_tile<T, true, false, TPW>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+    else if (wide) hipLaunchKernelGGL((k_tile<T, false, true, TPW>), dim3(grid), dim3(kTileThreads), 0, stream, args);
     else hipLaunchKernelGGL((k_tile<T, false, false, TPW>), dim3(grid), dim3(kTileThreads), 0, stream, args);
   } else {
     const unsigned grid = (unsigned)ntiles;
