@@ -158,13 +158,6 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
   unsigned long long t_loaded = 0, t_engine = 0;
 #endif
   const int tid = threadIdx.x;
-#ifdef QSIM_STAGGER
-  // (probe) the workgroups of the first dispatch round start together and stay in phase: offset the four that share a CU
-  if (blockIdx.x < 1024) {
-    const int steps = (blockIdx.x >> 8) & 3;
-    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(QSIM_STAGGER);
-  }
-#endif
   int hs[NH];                                         // the tile's high bits, pinned to scalar registers
 #pragma unroll
   for (int j = 0; j < NH; ++j) hs[j] = __builtin_amdgcn_readfirstlane((int)a.h[j]);
@@ -189,11 +182,10 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
   // Which tile a workgroup takes: TPW consecutive tiles per workgroup; order 0 = consecutive tiles in flight,
   // 1 = hashed, 2 = bit-reversed (probe build only, see tile_order_for).  ntiles is a power of two.
   auto tile_base = [&](unsigned i) -> u64 {
-#ifdef QSIM_TILE_STRIDED
-    unsigned tile = blockIdx.x + i * gridDim.x;       // (probe) the workgroups in flight cover consecutive tiles at every step
-#else
+    // (consecutive tiles per workgroup, workgroups dealt round-robin over the XCDs; measured against it,
+    // profiles/r02z_*: one contiguous eighth of the tiles per XCD +1.1 %, the two tiles half the state apart +4.7 %,
+    // a staggered start of the first round of workgroups 0.0 %)
     unsigned tile = blockIdx.x * TPW + i;
-#endif
 #ifdef QSIM_PROBES
     if ((a.order & kTileOrderMask) == 1) tile = (tile * 0x9E3779B1u) & (a.ntiles - 1);
     if ((a.order & kTileOrderMask) == 2) tile = a.ntiles > 1 ? __brev(tile) >> (__clz(a.ntiles) + 1) : 0;

@@ -610,7 +610,7 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
           for (unsigned c = b & (b - 1); c; c &= c - 1) {
             const unsigned own = (a & -a) | (b & -b) | (c & -c);
             const int count = select(own, nullptr, nullptr);
-            if (score(count, own) > best_score) { best_score = score(count, own); best_count = count; best_own = own; }
+            if (count > 0 && score(count, own) > best_score) { best_score = score(count, own); best_count = count; best_own = own; }
           }
     }
     std::vector<size_t> grp;          // indices into members

@@ -44,6 +44,25 @@ def test_direct_layouts_of_full_tiles():
         assert int(img["T"]) < 11 and not int(img["order"]) & (ti.DIRECT_IN | ti.DIRECT_OUT)
 
 
+def test_staging_swap_lists_on_line_bits_plan():
+    """The chunked runner applies a staging SWAP list whose local bits lie inside a 128-B line as ONE fused pass of
+    SWAP gates (runner/single_node.py): every such list must plan (regression: the first group's preference for a
+    triple above the line bits once picked a triple that held no op) and act as the permutation."""
+    import itertools
+    SW = orc.gate_matrix("SWAP", {})
+    for n in (9, 11, 12):
+        for m in (1, 2, 3):
+            for los in itertools.combinations(range(4), m):
+                ops = [([lo, hi], SW) for lo, hi in zip(los, range(n - m, n))]
+                images = ti.plan(n, ops)
+                if los == (0, 1, 2) or m == 1:
+                    psi = _rand_state(n, 7 * n + m)
+                    want = psi.copy()
+                    orc.apply_ops(want, ops)
+                    ti.run(psi, images)
+                    np.testing.assert_allclose(psi, want, rtol=0, atol=1e-13)
+
+
 def test_phase_runs_are_merged_and_ordered():
     """QFT: the CR(k, a), CR(k, b), CR(k, c) of a register group share one descriptor, and every
     merged run is written out before the next Hadamard on one of its bits."""
