@@ -62,6 +62,8 @@ while time.time() - t0 < budget:
             worst = max(worst, err)
             assert err < 1e-10, (n, cs, kw, err)
     cases += 1
+    if cases % 50 == 0:
+        print(f"... {cases} cases, {time.time() - t0:.0f} s, worst {worst:.2e}", flush=True)   # (a silent run is taken for hung)
 # large states, every gate kind, against the C oracle: many waves per SIMD, full tiles, 32-bit and (n >= 29)
 # 64-bit thread offsets are NOT reached here -- the 33-qubit tests of test_gpu_kernels cover those
 from oracle import c_oracle  # noqa: E402
@@ -82,5 +84,6 @@ while time.time() - t1 < budget * 0.5:
     worst = max(worst, err)
     assert err < 1e-10, ("big", n, seed, err)
     big_cases += 1
+    print(f"... large case {big_cases}: n = {n}, {len(ops)} ops, err {err:.2e}", flush=True)
 print(f"stress ok: {big_cases} large cases (21-25 qubits, fused) in {time.time() - t1:.0f} s")
 print(f"stress ok: {cases} random cases in {time.time() - t0:.0f} s, worst |diff| = {worst:.2e}")

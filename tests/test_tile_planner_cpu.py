@@ -63,6 +63,25 @@ def test_staging_swap_lists_on_line_bits_plan():
                     np.testing.assert_allclose(psi, want, rtol=0, atol=1e-13)
 
 
+def test_two_qubit_heavy_lists_plan_and_run():
+    """Lists made of dense 4x4 gates only (each claims two register bits, so groups hold one or two of them): random
+    pairs, many seeds, full and partial tiles -- every list plans, and the planned passes equal the oracle."""
+    rng = np.random.default_rng(4242)
+    for case in range(40):
+        n = int(rng.integers(8, 14))
+        ops = []
+        for _ in range(int(rng.integers(1, 12))):
+            a, b = (int(x) for x in rng.choice(n, size=2, replace=False))
+            g = rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4))
+            q, _ = np.linalg.qr(g)
+            ops.append(([a, b], q if rng.random() < 0.5 else orc.gate_matrix("SWAP", {})))
+        psi = _rand_state(n, 600 + case)
+        want = psi.copy()
+        orc.apply_ops(want, ops)
+        ti.run(psi, ti.plan(n, ops))
+        np.testing.assert_allclose(psi, want, rtol=0, atol=1e-12, err_msg=str(case))
+
+
 def test_phase_runs_are_merged_and_ordered():
     """QFT: the CR(k, a), CR(k, b), CR(k, c) of a register group share one descriptor, and every
     merged run is written out before the next Hadamard on one of its bits."""
