@@ -57,8 +57,8 @@ PAD_AFTER = os.environ.get("QS_GEN_PAD_AFTER", "")      # ... the same after the
 OPC = dict(NOP=0, DENSE1=1, SWAP1=10, ANTI1=19, PHASE=28, DENSE2=36, REAL1=45, YLIKE1=54,
            PHASE_NEG=63, PHASE_I=71, PHASE_NI=79, DIAGR=87,
            PRED_OUTER=91, PRED_LANE=92, GROUP=93, GROUP_FIRST=94, END=95, HAD1=96, SCALE=105, ASWAP1=106,
-           GROUP_DIRECT=115, END_DIRECT=116)
-NENT = 117
+           GROUP_DIRECT=115, END_DIRECT=116, PRED_OUTER_ZERO=117)
+NENT = 118
 
 BANK = {"A": 36, "B": 52}                # s32 (the ABI stack pointer) is reserved: banks start at s36
 E = 68                                   # overflow bank s[68:83]
@@ -430,6 +430,8 @@ def engine(partial: bool) -> list[str]:
                 a(f"s_branch {lab('pred_outer_' + bank)}")
             elif e == OPC["PRED_LANE"]:
                 a(f"s_branch {lab('pred_lane_' + bank)}")
+            elif e == OPC["PRED_OUTER_ZERO"]:
+                a(f"s_branch {lab('pred_outer_zero_' + bank)}")
             elif e == OPC["GROUP"]:
                 a(f"s_branch {lab('group_' + bank)}")
             elif e == OPC["GROUP_FIRST"]:
@@ -466,6 +468,14 @@ def engine(partial: bool) -> list[str]:
         a.label("pred_outer_" + bank)
         a(f"s_and_b32 s18, {HD(bank, 2)}, s19")
         a(f"s_cmp_lg_u32 s18, {HD(bank, 2)}")
+        a(f"s_cbranch_scc1 {lab('top_' + other(bank))}")
+        a(f"s_lshr_b32 s18, {HD(bank, 3)}, 16")
+        dispatch(a, bank, "s18")
+        # ... and its complement: the listed index bits outside the tile must all be 0 (the control = 0 half of a
+        # controlled gate that was merged with the 1q gate next to it on its target, tile_planner.h)
+        a.label("pred_outer_zero_" + bank)
+        a(f"s_and_b32 s18, {HD(bank, 2)}, s19")
+        a("s_cmp_lg_u32 s18, 0")
         a(f"s_cbranch_scc1 {lab('top_' + other(bank))}")
         a(f"s_lshr_b32 s18, {HD(bank, 3)}, 16")
         dispatch(a, bank, "s18")

@@ -63,7 +63,8 @@ enum : uint8_t {
                                       // in the group touches the target or a register control          (0)
   OPC_GROUP_DIRECT = QS_ENT_GROUP_DIRECT,   // first group = the layout the kernel loaded the tile in (TileArgs::lay_in):
                                       // x0..x7 arrive in registers, no LDS read
-  OPC_END_DIRECT = QS_ENT_END_DIRECT  // last group = the layout the kernel stores in (lay_out): no LDS write-back
+  OPC_END_DIRECT = QS_ENT_END_DIRECT, // last group = the layout the kernel stores in (lay_out): no LDS write-back
+  OPC_PRED_OUTER_ZERO = QS_ENT_PRED_OUTER_ZERO   // gate with index bits outside the tile that must all be 0
 };
 // 1q variant: 0..2 = target register bit J, no register control; 3 + 2*J + k = control on the
 // k-th of the two other register bits (ascending)
@@ -73,7 +74,7 @@ static inline int opc_1q_variant(int J, int C) {
 
 // Record stream.  A record is a 16-byte header followed by its matrix doubles (padded to 16 bytes);
 // the engine fetches the first 64 bytes of every record with one s_load_dwordx16, one record ahead.
-//   gate:   d0 = 4 x entry (the case itself, or OPC_PRED_OUTER / OPC_PRED_LANE),
+//   gate:   d0 = 4 x entry (the case itself, or OPC_PRED_OUTER(_ZERO) / OPC_PRED_LANE),
 //           d1 = byte offset of the next record from the start of the kernel arguments,
 //           d2 = outer predicate (absolute index bits >> kTileLow that must be 1),
 //           d3 = lane predicate (tile bits, low half) | 4 x case entry << 16 (second dispatch of a predicated gate)
@@ -297,7 +298,8 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
 struct TileDesc {          // one gate of a register group, before serialisation
   uint8_t opcode;          // case entry
   uint16_t blk_mask;       // tile bits OUTSIDE the group that must be 1
-  u64 outer_mask;          // absolute index bits outside the tile that must be 1
+  u64 outer_mask;          // absolute index bits outside the tile that must be 1 ...
+  bool outer_zero;         // ... or, when set, that must all be 0 (no lane predicate then)
   int nd;                  // matrix doubles
   double m[32];
 };
@@ -365,7 +367,9 @@ static int serialize_pass(const std::vector<TileGroup>& groups, TileArgs* a) {
       if (!room(bytes)) return fail(QSIM_ERR_INVALID, "internal: pass record stream overflow");
       if ((d.outer_mask & ((1ull << kTileLow) - 1)) || (d.outer_mask >> kTileLow) > 0xFFFFFFFFull)
         return fail(QSIM_ERR_INVALID, "internal: outer predicate outside index bits %d..%d", kTileLow, kTileMaxQubits - 1);
-      const uint32_t entry = d.blk_mask ? OPC_PRED_LANE : (d.outer_mask ? OPC_PRED_OUTER : d.opcode);
+      if (d.outer_zero && (d.blk_mask || !d.outer_mask))
+        return fail(QSIM_ERR_INVALID, "internal: a zero-predicate needs outer bits and no lane bits");
+      const uint32_t entry = d.blk_mask ? OPC_PRED_LANE : (d.outer_mask ? (d.outer_zero ? OPC_PRED_OUTER_ZERO : OPC_PRED_OUTER) : d.opcode);
       put32(off + 0, 4u * entry);
       put32(off + 4, (uint32_t)(off + bytes));
       put32(off + 8, (uint32_t)(d.outer_mask >> kTileLow));

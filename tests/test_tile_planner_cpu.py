@@ -82,6 +82,37 @@ def test_two_qubit_heavy_lists_plan_and_run():
         np.testing.assert_allclose(psi, want, rtol=0, atol=1e-12, err_msg=str(case))
 
 
+def test_outer_controlled_gate_merges_with_the_1q_gate_on_its_target():
+    """A controlled gate whose control lies outside the tile, next to a plain 1q gate U on its target, is written as
+    two predicated 2x2 records (control = 1: U V or V U; control = 0: U under OPC_PRED_OUTER_ZERO) instead of V + U
+    (csrc/tile_planner.h, emit_groups peephole).  Both orders, CNOT and CY, a gate in between on another qubit, and
+    the cases that must NOT pair (a gate on the target in between; a control inside the tile)."""
+    n = 13
+    H, X, RY, T, Y = (orc.gate_matrix(g, {"theta": 0.7}) for g in ("H", "X", "RY", "T", "Y"))
+    CNOT, CY = orc.gate_matrix("CNOT", {}), orc.gate_matrix("CY", {})
+    fill = [([q], H) for q in (3, 4, 7, 8, 9, 10)]  # with targets 5 and 6 the tile's high bits are 3..10: qubits 11, 12 stay outside
+
+    def zero_records(ops):
+        return sum(1 for img in ti.plan(n, ops) for r in ti.records(img) if r[0] == "gate" and r[3] < 0)
+
+    cases = [
+        (fill + [([12, 5], CNOT), ([5], RY)], 1),                       # V then U
+        (fill + [([5], RY), ([12, 5], CNOT), ([5], T)], 1),             # U then V (something later touches the target)
+        (fill + [([12, 5], CY), ([7], RY), ([5], RY)], 1),              # a gate on another qubit in between
+        (fill + [([12, 5], CNOT), ([12, 6], CNOT), ([5], RY), ([6], Y)], 2),
+        (fill + [([12, 5], CNOT), ([5], T), ([5], RY)], 0),             # T on the target sits in between
+        (fill + [([4, 5], CNOT), ([5], RY)], 0),                        # control inside the tile
+        (fill + [([5], RY), ([12, 5], CNOT)], 0),                       # nothing later on the target: the CNOT sinks instead
+    ]
+    for seed, (ops, want_zero) in enumerate(cases):
+        psi = _rand_state(n, 70 + seed)
+        want = psi.copy()
+        orc.apply_ops(want, ops)
+        ti.run(psi, ti.plan(n, ops))
+        np.testing.assert_allclose(psi, want, rtol=0, atol=1e-13, err_msg=str(seed))
+        assert zero_records(ops) == want_zero, (seed, zero_records(ops))
+
+
 def test_phase_runs_are_merged_and_ordered():
     """QFT: the CR(k, a), CR(k, b), CR(k, c) of a register group share one descriptor, and every
     merged run is written out before the next Hadamard on one of its bits."""

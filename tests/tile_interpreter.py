@@ -19,7 +19,7 @@ IMAGE_BYTES = 4096
 STREAM_OFF = 48                    # byte offset of the first record (csrc/tile_kernel.h)
 OPC = dict(DENSE1=1, SWAP1=10, ANTI1=19, PHASE=28, DENSE2=36, REAL1=45, YLIKE1=54, PHASE_NEG=63,
            PHASE_I=71, PHASE_NI=79, DIAGR=87, PRED_OUTER=91, PRED_LANE=92, GROUP=93, GROUP_FIRST=94, END=95,
-           HAD1=96, SCALE=105, ASWAP1=106, GROUP_DIRECT=115, END_DIRECT=116)
+           HAD1=96, SCALE=105, ASWAP1=106, GROUP_DIRECT=115, END_DIRECT=116, PRED_OUTER_ZERO=117)
 DIRECT_IN, DIRECT_OUT = 0x10, 0x20     # TileArgs::order flags
 _FAMILIES = ("DENSE1", "SWAP1", "ANTI1", "PHASE", "DENSE2", "REAL1", "YLIKE1", "PHASE_NEG", "PHASE_I", "PHASE_NI", "DIAGR",
              "HAD1", "SCALE", "ASWAP1")
@@ -91,6 +91,9 @@ def records(img):
             outer = int(d[2]) << 3
             if entry == OPC["PRED_LANE"]:
                 assert blk
+            elif entry == OPC["PRED_OUTER_ZERO"]:      # the listed outer bits must all be 0: reported as a NEGATIVE mask
+                assert outer and not blk
+                outer = -outer
             elif entry == OPC["PRED_OUTER"]:
                 assert outer and not blk
             else:
@@ -121,8 +124,8 @@ def plan(n_qubits: int, ops) -> np.ndarray:
     return out
 
 
-def _apply_1q(psi, idx, t_bit, U, cond_mask):
-    lo = idx[((idx >> t_bit) & 1 == 0) & ((idx & cond_mask) == cond_mask)]
+def _apply_1q(psi, idx, t_bit, U, cond_mask, zero_mask=0):
+    lo = idx[((idx >> t_bit) & 1 == 0) & ((idx & cond_mask) == cond_mask) & ((idx & zero_mask) == 0)]
     hi = lo | (1 << t_bit)
     a, b = psi[lo].copy(), psi[hi].copy()
     psi[lo] = U[0, 0] * a + U[0, 1] * b
@@ -140,6 +143,11 @@ def _apply_2q(psi, idx, qa_bit, qb_bit, U, cond_mask):
 
 def _c(v):
     return complex(v[0], v[1])
+
+
+def fam_of(op: int) -> str:
+    base = max(OPC[f] for f in _FAMILIES if OPC[f] <= op)
+    return next(k for k in _FAMILIES if OPC[k] == base)
 
 
 def run_pass(psi: np.ndarray, img) -> int:
@@ -174,8 +182,13 @@ def run_pass(psi: np.ndarray, img) -> int:
             A = [abs_bit(b) for b in s]                                 # absolute index bit of register bit j
             continue
         _, op, blk, outer, dbl, tail, size = rec
+        zero_mask = 0
+        if outer < 0:                      # OPC_PRED_OUTER_ZERO
+            zero_mask, outer = -outer, 0
         assert not (blk & sum(1 << b for b in s)), "lane predicate on a register bit"
-        assert not (outer & sum(1 << abs_bit(b) for b in range(T))), "outer predicate on a tile bit"
+        assert not ((outer | zero_mask) & sum(1 << abs_bit(b) for b in range(T))), "outer predicate on a tile bit"
+        if zero_mask:                      # only what the planner pairs: plain 1q gates (no register control)
+            assert fam_of(op) in ("DENSE1", "REAL1", "ANTI1", "YLIKE1") and op - OPC[fam_of(op)] < 3, op
         cond = abs_mask(blk) | outer
         fam = max(OPC[f] for f in _FAMILIES if OPC[f] <= op)
         var = op - fam
@@ -221,7 +234,7 @@ def run_pass(psi: np.ndarray, img) -> int:
                 u11 = tail(16)
                 U = np.array([[_c(m[0:2]), _c(m[2:4])], [_c(m[4:6]), _c(u11)]])
                 assert size == 80
-            _apply_1q(psi, idx, A[J], U, cond | (0 if ctrl is None else 1 << A[ctrl]))
+            _apply_1q(psi, idx, A[J], U, cond | (0 if ctrl is None else 1 << A[ctrl]), zero_mask)
         elif fam in (OPC["PHASE"], OPC["PHASE_NEG"], OPC["PHASE_I"], OPC["PHASE_NI"]):
             assert 0 <= var < 8
             if fam == OPC["PHASE"]:
