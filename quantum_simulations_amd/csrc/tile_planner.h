@@ -802,6 +802,17 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
   // (tools/gate_cost_probe.py), so holding more than kSaturated ops buys nothing: a first-come pass
   // that is already that full is kept (phase-heavy circuits: QFT).
   constexpr int kSaturated = 64;
+  // Memory pattern of a tile (profiles/r02z_tile_bits_samples.txt, 2500 gate-less passes): index bits b and b + 7
+  // with b = 13..16 in ONE tile cost +0.13-0.17 ms each at 28 qubits (+9 %; byte-address bits 17-20 select the
+  // bank, 24-27 are row bits folded into it: both varying inside a tile puts two rows on one bank), bits 18 / 26 and
+  // 19 / 27 half of that.  Counted in units of ops a pass holds (tuning().plan_conflict_cost each).
+  auto conflicts = [&](u64 mask) -> int {
+    int c = 0;
+    for (int b = 13; b <= 16; ++b) c += 2 * (int)(((mask >> b) & (mask >> (b + 7)) & 1));
+    for (int b = 18; b <= 19; ++b) c += (int)(((mask >> b) & (mask >> (b + 8)) & 1));
+    return c;
+  };
+  auto penalty = [&](u64 mask) -> int { return tune.plan_conflict_cost * conflicts(mask) / 2; };
   auto mask_of = [](const std::vector<int>& bits, size_t n) { u64 m = 0; for (size_t i = 0; i < n && i < bits.size(); ++i) m |= 1ull << bits[i]; return m; };
   // candidate tiles for the next pass from the current `done` / `first`: [0] = first come, then the
   // look-ahead ones grown from the first `seed` claimed bits
@@ -827,10 +838,10 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
     for (size_t seed = 0; seed <= max_seed && seed <= claimed.size(); seed += seed_step) {
       u64 mask = mask_of(claimed, seed);
       while (__builtin_popcountll(mask) < cap) {
-        int pick = -1, pick_count = -1;
+        int pick = -1, pick_count = -(1 << 20);
         for (int b = low; b < k; ++b) {
           if ((mask >> b) & 1) continue;
-          const int c = holds(mask | (1ull << b), nullptr);
+          const int c = holds(mask | (1ull << b), nullptr) - penalty(mask | (1ull << b));
           if (c > pick_count) { pick_count = c; pick = b; }
         }
         if (pick < 0) break;
@@ -846,10 +857,10 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
     while (first < n_ops && done[first]) ++first;
     candidates(&cands, 6, 2);
     u64 best_mask = cands[0];
-    int best_score = -1;
+    int best_score = -(1 << 20);
     for (size_t ci = 0; ci < cands.size(); ++ci) {
       trial.clear();
-      int score = std::min(holds(cands[ci], &trial), kSaturated);
+      int score = std::min(holds(cands[ci], &trial), kSaturated) - penalty(cands[ci]);
       if (depth2 && cands.size() > 1 && trial.size() < remaining) {
         // what the pass AFTER this one could hold (a smaller candidate set)
         const size_t first_saved = first;
@@ -857,7 +868,7 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
         while (first < n_ops && done[first]) ++first;
         candidates(&cands2, 4, 4);
         int next_best = 0;
-        for (u64 m2 : cands2) next_best = std::max(next_best, std::min(holds(m2, nullptr), kSaturated));
+        for (u64 m2 : cands2) next_best = std::max(next_best, std::min(holds(m2, nullptr), kSaturated) - penalty(m2));
         for (size_t i : trial) done[i] = 0;
         first = first_saved;
         score += next_best;
@@ -873,7 +884,7 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
     if (members.empty()) return fail(QSIM_ERR_INVALID, "internal: fused planner made no progress");
     // fill the tile with the lowest unused bits so it always has T bits
     for (int b = low; (int)high.size() < cap && b < k; ++b)
-      if (std::find(high.begin(), high.end(), b) == high.end()) high.push_back(b);
+      if (std::find(high.begin(), high.end(), b) == high.end()) high.push_back(b);   // (bits 3.. conflict with nothing)
     std::sort(high.begin(), high.end());
 #ifdef QSIM_PROBES
     if (tune.debug_skip_gates == 2) for (int j = 0; j < cap; ++j) high[j] = low + j;   // contiguous tiles (floor probe)
