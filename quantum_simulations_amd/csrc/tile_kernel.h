@@ -29,8 +29,11 @@ constexpr int kTileLow = QSIM_TILE_LOW;
 #endif
 constexpr int kTileBitsMax = QSIM_TILE_BITS_MAX;       // 2^11 amplitudes = 32 KiB of LDS: 5 workgroups per CU
 constexpr int kGroupBits = 3;
-constexpr int kTileThreads = 256;
-constexpr int kTileThreadBits = 8;
+#ifndef QSIM_TILE_THREAD_BITS
+#define QSIM_TILE_THREAD_BITS 8                        // (9 with QSIM_TILE_BITS_MAX = 12: 512 threads on a 64 KiB tile, probe)
+#endif
+constexpr int kTileThreadBits = QSIM_TILE_THREAD_BITS;
+constexpr int kTileThreads = 1 << kTileThreadBits;
 constexpr int kTileMaxQubits = 35;     // outer predicates are 32-bit masks over index bits 3..34
 
 // Entries of the engine's branch table (header dword 0 of a record = 4 x entry).
@@ -82,7 +85,7 @@ static inline int opc_1q_variant(int J, int C) {
 //           d5..d11 = LDS byte-address XOR constants of registers x1..x7 (lds_slot is linear over GF(2))
 //   end:    d0 = 4 x OPC_END(_DIRECT), d1 = its own offset
 constexpr int kTileArgBytes = 4096;
-constexpr int kTileStreamOff = 48;                       // byte offset of the first record
+constexpr int kTileStreamOff = 64;                       // byte offset of the first record
 constexpr int kTileStreamBytes = kTileArgBytes - kTileStreamOff;
 constexpr int kTileStreamSlack = 48;                     // the 64-byte fetch of the END record stays inside the block
 
@@ -99,8 +102,9 @@ struct TileArgs {
   // Through LDS (no direct flag) both are h[0..7] in order (element tid + 256 j of the tile).  Direct: lay_in[5..7] are
   // the bits of the FIRST register group (all above the line bits), lay_in[0..4] the other tile bits ascending --
   // what the thread then holds IS the group's x0..x7; lay_out likewise for the LAST group.
-  uint8_t lay_in[8];
-  uint8_t lay_out[8];
+  uint8_t lay_in[12];
+  uint8_t lay_out[12];
+  uint8_t pad_[8];
   uint32_t stream[kTileStreamBytes / 4];
 };
 constexpr uint8_t kTileDirectIn = 0x10, kTileDirectOut = 0x20, kTileOrderMask = 0x03;
@@ -120,7 +124,8 @@ __host__ __device__ __forceinline__ unsigned lds_slot(unsigned t) { return t ^ (
 // later); tiles of a workgroup half the state apart instead of adjacent -- 4.7 % slower (adjacent tiles share DRAM pages).
 constexpr int tile_waves(int T, int tiles_per_wg = 1) {
   const int granules = ((1 << T) * 16 + 1279) / 1280;
-  return 128 / granules > 5 ? 5 : 128 / granules;   // (small tiles: 5 as before, their kernels use < 96 VGPRs anyway)
+  const int per_simd = (128 / granules) * (kTileThreads / 256);   // workgroups per CU x waves per SIMD of one workgroup
+  return per_simd > 5 ? 5 : (per_simd < 1 ? 1 : per_simd);      // (small tiles: 5 as before, their kernels use < 96 VGPRs anyway)
 }
 
 // TPW tiles per workgroup (1 or 2): with 2, the second tile's global loads are issued BEFORE the gate engine

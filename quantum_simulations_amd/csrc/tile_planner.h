@@ -103,7 +103,7 @@ static int tile_order_for(const TileArgs&, int) {
 
 template <int T>
 static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t stream, double alg_bytes) {
-  if constexpr (T > kTileBitsMax) {
+  if constexpr (T > kTileBitsMax || T < kTileThreadBits) {
     return fail(QSIM_ERR_INVALID, "internal: tile size %d not built", T);
   } else {
   const u64 ntiles = 1ull << (c->k - T);
@@ -281,7 +281,7 @@ static void commute_fuse_1q(std::vector<FusedOp>* ops, bool backward) {
   ops->resize(w);
 }
 
-constexpr int kTileMinChunk = 8;   // smaller chunks run gate by gate
+constexpr int kTileMinChunk = kTileThreadBits > 8 ? kTileThreadBits : 8;   // smaller chunks run gate by gate (a tile holds at least one amplitude per thread)
 
 
 // The case an op gets once its register positions are known depends only on its kind and matrix:

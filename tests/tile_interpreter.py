@@ -16,7 +16,7 @@ from quantum_simulations_amd import _lib
 from quantum_simulations_amd.kernel.device import pack_ops
 
 IMAGE_BYTES = 4096
-STREAM_OFF = 48                    # byte offset of the first record (csrc/tile_kernel.h)
+STREAM_OFF = 64                    # byte offset of the first record (csrc/tile_kernel.h)
 OPC = dict(DENSE1=1, SWAP1=10, ANTI1=19, PHASE=28, DENSE2=36, REAL1=45, YLIKE1=54, PHASE_NEG=63,
            PHASE_I=71, PHASE_NI=79, DIAGR=87, PRED_OUTER=91, PRED_LANE=92, GROUP=93, GROUP_FIRST=94, END=95,
            HAD1=96, SCALE=105, ASWAP1=106, GROUP_DIRECT=115, END_DIRECT=116, PRED_OUTER_ZERO=117)
@@ -24,7 +24,7 @@ DIRECT_IN, DIRECT_OUT = 0x10, 0x20     # TileArgs::order flags
 _FAMILIES = ("DENSE1", "SWAP1", "ANTI1", "PHASE", "DENSE2", "REAL1", "YLIKE1", "PHASE_NEG", "PHASE_I", "PHASE_NI", "DIAGR",
              "HAD1", "SCALE", "ASWAP1")
 _IMAGE = np.dtype([("amp", "<u8"), ("nrec", "<i4"), ("T", "<i4"), ("h", "u1", (11,)), ("order", "u1"), ("ntiles", "<u4"),
-                   ("lay_in", "u1", (8,)), ("lay_out", "u1", (8,)),
+                   ("lay_in", "u1", (12,)), ("lay_out", "u1", (12,)), ("pad_", "u1", (8,)),
                    ("stream", "u1", (IMAGE_BYTES - STREAM_OFF,))])
 assert _IMAGE.itemsize == IMAGE_BYTES
 
