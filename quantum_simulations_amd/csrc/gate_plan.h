@@ -44,7 +44,7 @@ struct Tuning {
   int tile_commute_fuse = 0; // (off: neutral over 8 circuits -- 1 % less per pass, one pass more -- profiles/r02y_ab_commute_fusion.txt)
                              // a 1q gate moves past ops it commutes with and merges with its neighbour 1q gate on the qubit: 0 off, 1 forward (the earlier gate moves), 2 backward (the later one moves: fewer passes)
   int tile_mux = 1;          // a controlled gate with its control outside the tile + the 1q gate next to it on its target -> two predicated 2x2 records
-  int plan_conflict_cost = 0; // pass builder: ops a pass must hold more to be worth one bank / row conflict pair of tile bits
+  int plan_conflict_cost = -1; // pass builder, bank / row conflict pairs of tile bits: > 0 = ops a pass must hold more to be worth one (costs passes), -1 = break ties only (-1.9 % over 8 circuits), 0 = ignore
   int tile_sink_swaps = 1;   // X / CNOT that nothing later in their group touches: swap LDS addresses at write-back (OPC_ASWAP1)
   int tile_group_search = 1; // register groups: try every triple of pending target bits, not only first come
   int tile_had = QSIM_TILE_HAD_DEFAULT;          // uncontrolled c [[1,1],[1,-1]] as add/sub butterflies + one scale per pass (OPC_HAD1 / OPC_SCALE)
