@@ -27,7 +27,7 @@ constexpr int kTileLow = QSIM_TILE_LOW;
 #ifndef QSIM_TILE_BITS_MAX
 #define QSIM_TILE_BITS_MAX 11
 #endif
-constexpr int kTileBitsMax = QSIM_TILE_BITS_MAX;       // 2^11 amplitudes = 32 KiB of LDS: 5 workgroups per CU
+constexpr int kTileBitsMax = QSIM_TILE_BITS_MAX;       // 2^11 amplitudes = 32 KiB of LDS: 4 workgroups per CU (1280-byte LDS granules, see tile_waves)
 constexpr int kGroupBits = 3;
 #ifndef QSIM_TILE_THREAD_BITS
 #define QSIM_TILE_THREAD_BITS 8                        // (9 with QSIM_TILE_BITS_MAX = 12: 512 threads on a 64 KiB tile, probe)
