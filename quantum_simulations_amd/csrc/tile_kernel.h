@@ -104,7 +104,7 @@ struct TileArgs {
   // what the thread then holds IS the group's x0..x7; lay_out likewise for the LAST group.
   uint8_t lay_in[12];
   uint8_t lay_out[12];
-  uint8_t pad_[8];
+  double2* amp_out;        // probe build only: store the tiles here instead of in place (nullptr: in place)
   uint32_t stream[kTileStreamBytes / 4];
 };
 constexpr uint8_t kTileDirectIn = 0x10, kTileDirectOut = 0x20, kTileOrderMask = 0x03;
@@ -190,7 +190,8 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
   auto tile_base = [&](unsigned i) -> u64 {
     // (consecutive tiles per workgroup, workgroups dealt round-robin over the XCDs; measured against it,
     // profiles/r02z_*: one contiguous eighth of the tiles per XCD +1.1 %, the two tiles half the state apart +4.7 %,
-    // a staggered start of the first round of workgroups 0.0 %)
+    // a staggered start of the first round of workgroups 0.0 %, the first two tiles' loads issued together / two tiles
+    // ahead with four per workgroup 0.0 % / still +1 %, tiles stored into a second buffer instead of in place +6 %)
     unsigned tile = blockIdx.x * TPW + i;
 #ifdef QSIM_PROBES
     if ((a.order & kTileOrderMask) == 1) tile = (tile * 0x9E3779B1u) & (a.ntiles - 1);
@@ -207,16 +208,16 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
   typedef double amp_t __attribute__((ext_vector_type(2)));   // one amplitude as a 128-bit register operand of the engine
   typedef __attribute__((address_space(1))) amp_t gamp_t;     // ... in global memory: global_*, not flat_* (a flat access
                                                               // also counts on lgkmcnt, which the engine waits on per record)
-  auto element = [&](u64 base, int j, off_t toff, const int* rbits) -> gamp_t* {
+  auto element = [&](u64 base, int j, off_t toff, const int* rbits, double2* amp) -> gamp_t* {
     u64 oj = 0;
 #pragma unroll
     for (int i = 0; i < NH - NTB; ++i) oj |= (u64)((j >> i) & 1) << rbits[i];
     if constexpr (WIDE) {
-      return (gamp_t*)(u64)(a.amp + base + toff + oj);
+      return (gamp_t*)(u64)(amp + base + toff + oj);
     } else {
       // wave-uniform row base pinned to scalar registers + 32-bit thread offset: `global_* v, voff, s[row]`,
       // no 64-bit vector address is formed (or kept alive across the engine)
-      const u64 r = reinterpret_cast<u64>(a.amp + base + oj);
+      const u64 r = reinterpret_cast<u64>(amp + base + oj);
       const u64 row = ((u64)__builtin_amdgcn_readfirstlane((unsigned)(r >> 32)) << 32) |
                       (unsigned)__builtin_amdgcn_readfirstlane((unsigned)r);
       unsigned tb = toff << 4;
@@ -226,13 +227,18 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
   };
   auto load = [&](gamp_t* p) -> amp_t { return NT ? __builtin_nontemporal_load(p) : *p; };
   auto store = [&](gamp_t* p, amp_t v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; };
+#ifdef QSIM_PROBES
+  double2* const dst = a.amp_out ? a.amp_out : a.amp;
+#else
+  double2* const dst = a.amp;
+#endif
   const unsigned slot0 = lds_slot(tid);               // element tid + BLOCK * j sits BLOCK * j slots further (the swizzle uses bits 4-7 only)
   static_assert(BLOCK >= 256, "lds_slot(tid + BLOCK * j) = lds_slot(tid) + BLOCK * j needs BLOCK to be a multiple of 256");
   amp_t* const tile = reinterpret_cast<amp_t*>(lds);
   u64 base = tile_base(0);
   amp_t v[PER];
 #pragma unroll
-  for (int j = 0; j < PER; ++j) v[j] = load(element(base, j, tin, rin));
+  for (int j = 0; j < PER; ++j) v[j] = load(element(base, j, tin, rin, a.amp));
 #pragma unroll 1
   for (int it = 0; it < TPW; ++it) {                  // (rolled: one copy of the 92 KiB engine)
     // the engine's x0..x7 (pinned to v[4:35]): the loaded tile itself when the first register group is the load
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
     if (it + 1 < TPW) {
       base = tile_base(it + 1);
 #pragma unroll
-      for (int j = 0; j < PER; ++j) v[j] = load(element(base, j, tin, rin));
+      for (int j = 0; j < PER; ++j) v[j] = load(element(base, j, tin, rin, a.amp));
     }
 #ifdef QSIM_PROBES
     if (it == 0) t_loaded = __builtin_readcyclecounter();
@@ -279,13 +285,13 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
 #endif
     if (dout) {                                       // (host: only full tiles, PER == 8)
 #pragma unroll
-      for (int j = 0; j < PER; ++j) store(element(cur, j, tout, rout), x[j < 8 ? j : 0]);
+      for (int j = 0; j < PER; ++j) store(element(cur, j, tout, rout, dst), x[j < 8 ? j : 0]);
     } else {
       amp_t w[PER];
 #pragma unroll
       for (int j = 0; j < PER; ++j) w[j] = tile[slot0 + BLOCK * j];
 #pragma unroll
-      for (int j = 0; j < PER; ++j) store(element(cur, j, tout, rout), w[j]);
+      for (int j = 0; j < PER; ++j) store(element(cur, j, tout, rout, dst), w[j]);
     }
     // the next tile's first LDS write (by the kernel or by the engine's first group change) must not overtake a
     // wave still reading this tile's last group / result

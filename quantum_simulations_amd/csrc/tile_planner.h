@@ -112,6 +112,13 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   args.ntiles = (uint32_t)ntiles;
   args.order = (uint8_t)((a.order & ~kTileOrderMask) | (tile_order_for(a, T) & kTileOrderMask));
 #ifdef QSIM_PROBES
+  if (getenv("QSIM_DEBUG_OUT_OF_PLACE")) {   // memory probe (WRONG results): tiles are stored into a second buffer
+    static double2* other = nullptr;
+    static size_t other_bytes = 0;
+    const size_t need = sizeof(double2) << c->k;
+    if (other_bytes < need) { if (other) (void)hipFree(other); (void)hipMalloc((void**)&other, need); other_bytes = need; }
+    args.amp_out = other;
+  }
   {   // in-kernel stamps: QSIM_DEBUG_STAMPS=<file> dumps entry / loaded / engine / stored cycle stamps of every 64th workgroup
     static unsigned long long* dbuf = nullptr;
     static const char* path = getenv("QSIM_DEBUG_STAMPS");

@@ -24,7 +24,7 @@ DIRECT_IN, DIRECT_OUT = 0x10, 0x20     # TileArgs::order flags
 _FAMILIES = ("DENSE1", "SWAP1", "ANTI1", "PHASE", "DENSE2", "REAL1", "YLIKE1", "PHASE_NEG", "PHASE_I", "PHASE_NI", "DIAGR",
              "HAD1", "SCALE", "ASWAP1")
 _IMAGE = np.dtype([("amp", "<u8"), ("nrec", "<i4"), ("T", "<i4"), ("h", "u1", (11,)), ("order", "u1"), ("ntiles", "<u4"),
-                   ("lay_in", "u1", (12,)), ("lay_out", "u1", (12,)), ("pad_", "u1", (8,)),
+                   ("lay_in", "u1", (12,)), ("lay_out", "u1", (12,)), ("amp_out", "<u8"),
                    ("stream", "u1", (IMAGE_BYTES - STREAM_OFF,))])
 assert _IMAGE.itemsize == IMAGE_BYTES
 
