@@ -40,7 +40,7 @@ base = [3, 4, 5, 6, 7, 8, 9]
 if len(sys.argv) > 2:        # custom sets: "20,21,24;20,21,25;..." (padded with the low bits 3, 4, ...)
     for spec in sys.argv[2].split(";"):
         hs = [int(x) for x in spec.split(",")]
-        bits = base[:8 - len(hs)] + hs
+        bits = base[:max(0, 8 - len(hs))] + hs          # (nine bits for a 12-bit-tile build: given in full)
         print("set", hs, measure(bits), flush=True)
     sys.exit(0)
 print("contiguous", base + [10], measure(base + [10]), flush=True)
