@@ -225,8 +225,14 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
       return (gamp_t*)((__attribute__((address_space(1))) char*)row + tb);
     }
   };
-  auto load = [&](gamp_t* p) -> amp_t { return NT ? __builtin_nontemporal_load(p) : *p; };
-  auto store = [&](gamp_t* p, amp_t v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; };
+#ifndef QSIM_TILE_LOAD_NT
+#define QSIM_TILE_LOAD_NT 1      // (probe: 0 = plain loads resp. stores even for states beyond the Infinity Cache: +0.8 % / +2.3 %, profiles/r02z_ab_paired_stores.txt)
+#endif
+#ifndef QSIM_TILE_STORE_NT
+#define QSIM_TILE_STORE_NT 1
+#endif
+  auto load = [&](gamp_t* p) -> amp_t { return (NT && QSIM_TILE_LOAD_NT) ? __builtin_nontemporal_load(p) : *p; };
+  auto store = [&](gamp_t* p, amp_t v) { if (NT && QSIM_TILE_STORE_NT) __builtin_nontemporal_store(v, p); else *p = v; };
 #ifdef QSIM_PROBES
   double2* const dst = a.amp_out ? a.amp_out : a.amp;
 #else
