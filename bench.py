@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-sweep", action="store_true", help="skip the per-target sweeps (config 3)")
     ap.add_argument("--sweep-qubits", type=int, default=30)
+    ap.add_argument("--fused-qubits", type=int, default=30,
+                    help="N = 1: size of the second fused run (`fused30` sub-record; 0 = off)")
     ap.add_argument("--sustain-seconds", type=float, default=3.0,
                     help="second, longer timed region after the K-step one (0 = off)")
     ap.add_argument("--no-configs", action="store_true", help="N > 1: skip the config-4 / config-5 sub-runs")
@@ -154,18 +156,59 @@ def cpu_config1_columns() -> dict:
 
 
 def pmc_traffic_per_launch(kernel_prefix: str):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_summary.json, written by tools/pmc_summary.py; the newest round wins); None if absent."""
-    best = None
+    """(HBM bytes per launch of the dominant kernel, the summary it comes from) out of the committed rocprofv3 PMC
+    passes (profiles/*_pmc_summary.json, written by tools/pmc_summary.py) -- but only from a summary taken with
+    the kernel sources this run was built from (`csrc_sha16` == _lib.source_hash()); anything older is a stale
+    figure and is reported as null.  The PMC passes cannot run inside this process (rocprofv3 wraps it)."""
+    from quantum_simulations_amd._lib import source_hash
+    now = source_hash()
+    best = (None, None)
     for path in sorted((ROOT / "profiles").glob("*_pmc_summary.json")):
         try:
             doc = json.loads(path.read_text())
         except Exception:
             continue
+        if doc.get("csrc_sha16") != now:
+            continue
         for row in doc.get("kernels", []):
             if row.get("kernel", "").startswith(kernel_prefix) and row.get("hbm_bytes_per_launch"):
-                best = float(row["hbm_bytes_per_launch"])
+                best = (float(row["hbm_bytes_per_launch"]), f"profiles/{path.name}")
     return best
+
+
+def fused_run(n: int, depth: int, steps: int, warmup: int, device: int) -> dict:
+    """The fused workload at another size on a fresh state (N = 1: the 30-qubit random 1q+CX circuit, the largest
+    single-GPU configuration of BASELINE.json's list that bench.py times): passes, ms per pass by HIP events,
+    roofline fraction of the bytes the launches move, gate-applications/s by the host clock."""
+    from quantum_simulations_amd.circuits import random_1q_cx_circuit
+    from quantum_simulations_amd.runner.engine import SingleGpuEngine
+    eng = SingleGpuEngine(n, device=device, mode="fused")
+    circuit = random_1q_cx_circuit(n, depth=depth)
+    n_gates = len(circuit["gates"])
+    eng.init_zero_state()
+    plan = eng.plan(circuit, repeats=warmup + steps)
+    for _ in range(warmup):
+        eng.execute(plan)
+    eng.barrier()
+    eng.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.execute(plan)
+    eng.barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_end()
+    norm2 = eng.norm2()
+    passes = eng.passes_per_step(plan)
+    eng.close()
+    dom = max(prof, key=lambda e: e["total_ms"])
+    moved = dom["hbm_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
+    return {"workload": f"{n}-qubit random 1q+CX circuit depth {depth} (seed 20260228), {n_gates} gates, complex128, fused",
+            "n_qubits": n, "gates_per_step": n_gates, "steps": steps, "warmup": warmup,
+            "gate_apps_per_s": round(n_gates * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3),
+            "hbm_passes_per_step": passes, "kernel": dom["kernel"], "launches": dom["launches"],
+            "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4),
+            "bytes_per_launch": dom["hbm_bytes"] / dom["launches"],
+            "achieved_GBps": round(moved, 1), "frac": round(moved / HBM_PEAK_GBS, 4), "norm2_after": norm2}
 
 
 # ---------------------------------------------------------------------------------- N = 1
@@ -214,9 +257,10 @@ def run_single(args, k: int) -> tuple[dict, list[str]]:
     if dom:
         secs = dom["total_ms"] * 1e-3
         moved = dom["hbm_bytes"] / secs / 1e9
+        traffic, traffic_source = pmc_traffic_per_launch(dom["kernel"].split(" ")[0])
         roofline = {"bound": "hbm", "achieved": round(moved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(moved / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic_per_launch(dom["kernel"].split(" ")[0]),
+                    "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": dom["kernel"], "launches": dom["launches"],
                     "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4),
                     "bytes_per_launch": dom["hbm_bytes"] / dom["launches"],
@@ -246,6 +290,13 @@ def run_single(args, k: int) -> tuple[dict, list[str]]:
         "copy_ceiling": copy,
         "kernel_breakdown": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof],
     }
+    if args.fused_qubits and args.fused_qubits != n and args.mode == "fused":
+        # the same workload family at the largest single-GPU size of BASELINE.json's list (16 GiB state): ~2 s of GPU
+        # time, so the 30-qubit figure of the fused pass is timed by the driver's run and not only by profiles/
+        out["fused%d" % args.fused_qubits] = fused_run(args.fused_qubits, args.depth, steps=5, warmup=2,
+                                                        device=int(os.environ.get("LOCAL_RANK", "0")))
+        if abs(out["fused%d" % args.fused_qubits]["norm2_after"] - 1.0) > NORM_TOL:
+            invalid.append(f"fused{args.fused_qubits}: norm check failed")
     if not args.no_sweep:
         # BASELINE config 3 / north-star target: one gate per launch on a 30-qubit random state (no fusion
         # across the timed gates), every target index, fractions of the 8 TB/s peak of SURVEY 8d's

@@ -189,13 +189,17 @@ int qsim_time_end(qsim_chunk* c, float* elapsed_ms);       /* record + synchroni
  * returns, per kernel class, the launch count, the summed event time, the summed
  * algorithmic bytes (per gate-application 32 B per amplitude the gate touches,
  * summed over the gates of a launch -- a fused pass counts every gate it applies) and
- * hbm_bytes, the bytes the launches themselves had to move (32 B per amplitude touched once). */
+ * hbm_bytes, the bytes the launches themselves had to move (32 B per amplitude touched once);
+ * streaming_launches counts the launches that ran the non-temporal (Infinity-Cache bypassing)
+ * instantiation of their kernel -- the cache policy follows the size of the ALLOCATION a chunk
+ * lives in (a small view of a large parent streams), and tests assert on it. */
 typedef struct {
   char kernel[48];
   uint64_t launches;
   double total_ms;
   double algorithmic_bytes;
   double hbm_bytes;
+  uint64_t streaming_launches;
 } qsim_profile_entry;
 int qsim_profile_begin(qsim_chunk* c);
 int qsim_profile_end(qsim_chunk* c, int max_entries, int* n_entries, qsim_profile_entry* out);

@@ -93,9 +93,21 @@ SIGNATURES = {
 class ProfileEntry(C.Structure):
     _fields_ = [("kernel", C.c_char * 48), ("launches", C.c_uint64),
                 ("total_ms", C.c_double), ("algorithmic_bytes", C.c_double),
-                ("hbm_bytes", C.c_double)]
+                ("hbm_bytes", C.c_double), ("streaming_launches", C.c_uint64)]
 
 _lib = None
+
+
+def source_hash() -> str:
+    """sha256 (16 hex digits) over the kernel sources of libqsim_hip.so: measurement summaries under profiles/
+    record it, and bench.py prints a PMC traffic figure only from a summary taken with the same sources."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = Path(__file__).resolve().parent / "csrc"
+    for path in sorted(list(csrc.glob("*.h")) + list(csrc.glob("*.hip")) + list(csrc.glob("*.py")) + [csrc / "Makefile"]):
+        h.update(path.name.encode())
+        h.update(path.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def load() -> C.CDLL:

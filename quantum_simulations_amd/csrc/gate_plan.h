@@ -27,7 +27,7 @@ static inline bool is_one(double re, double im) { return re == 1.0 && im == 0.0;
 // Index bits below this are resolved across lanes (partners share one 128-B line).
 constexpr int kLaneCut = 3;
 
-// Tunables (environment overrides are for profiling sweeps only).
+// Tunables (environment overrides exist in the probe build only).
 #ifndef QSIM_TILE_HAD_DEFAULT
 #define QSIM_TILE_HAD_DEFAULT 1
 #endif
@@ -50,13 +50,17 @@ struct Tuning {
   int tile_had = QSIM_TILE_HAD_DEFAULT;          // uncontrolled c [[1,1],[1,-1]] as add/sub butterflies + one scale per pass (OPC_HAD1 / OPC_SCALE)
   int debug_skip_gates = 0;  // probe build only: QSIM_DEBUG_SKIP_GATES=1: tile passes move data but apply nothing (WRONG results)
   int tile_order = -1;       // probe build only: QSIM_TILE_ORDER=0/1/2 forces the tile order of k_tile
-  int debug_stats = 0;       // QSIM_DEBUG_STATS=1: print gates / groups per pass to stderr
+  int debug_stats = 0;       // probe build only: QSIM_DEBUG_STATS=1: print gates / groups per pass to stderr; 2: time every pass
   // States up to this size stay in the 256 MiB Infinity Cache between launches when accessed with
   // the default cache policy (tools/mall_probe.hip: 8.5-8.8 TB/s r+w for a 128-256 MiB region vs
   // 5.5 streaming); the NT policy bypasses it (6.0-6.2 at every size), so NT is for larger states.
   u64 mall_bytes = 256ull << 20;
   Tuning() {
-    // Planning knobs: every setting yields a correct program (tests plan under several of them).
+#ifdef QSIM_PROBES
+    // Every knob lives in the probe build only (`make probes` -> libqsim_hip_probes.so, loaded by tools/ and by the
+    // planner tests through QSIM_LIBRARY): the product library reads nothing from the environment, so a plan -- and a
+    // timed number -- never depends on it.  Planning knobs: every setting yields a correct program
+    // (tests/test_tile_planner_cpu.py plans and interprets under each of them).
     if (const char* e = getenv("QSIM_DEBUG_STATS")) debug_stats = atoi(e);
     if (const char* e = getenv("QSIM_PASS_GATES")) max_gates_per_pass = std::max(1, atoi(e));
     if (const char* e = getenv("QSIM_PLAN_LOOKAHEAD")) plan_lookahead = atoi(e);
@@ -70,9 +74,7 @@ struct Tuning {
     if (const char* e = getenv("QSIM_TILE_MUX")) tile_mux = atoi(e);
     if (const char* e = getenv("QSIM_TILE_COMMUTE_FUSE")) tile_commute_fuse = atoi(e);
     if (const char* e = getenv("QSIM_TILE_LAST_SEARCH")) tile_last_search = atoi(e);
-#ifdef QSIM_PROBES
-    // Probe knobs (cache policy, launch shapes, gate-less passes that give WRONG results): only in the
-    // probe build `make probes` -> libqsim_hip_probes.so that tools/ loads; the product library has none.
+    // Probe knobs (cache policy, launch shapes, gate-less passes that give WRONG results)
     if (const char* e = getenv("QSIM_MALL_BYTES")) mall_bytes = strtoull(e, nullptr, 10);
     if (const char* e = getenv("QSIM_SWZ_CUT")) swz_cut = atoi(e);
     if (const char* e = getenv("QSIM_NT")) force_nt = atoi(e);
@@ -94,6 +96,7 @@ struct LaunchRecord {
   int cls;            // kernel class id
   double bytes;       // algorithmic bytes: sum over the launch's gate-applications
   double hbm_bytes;   // bytes the launch itself has to move (32 B per amplitude it touches)
+  bool streaming;     // the non-temporal (Infinity-Cache bypassing) instantiation ran
   hipEvent_t e0, e1;
 };
 struct ProfileState {
@@ -123,11 +126,12 @@ static hipEvent_t prof_event() {
 struct ProfileScope {  // RAII around one launch
   bool on;
   LaunchRecord rec;
-  ProfileScope(int cls, double bytes, hipStream_t stream, double hbm_bytes = -1.0) {
+  ProfileScope(int cls, double bytes, hipStream_t stream, bool streaming, double hbm_bytes = -1.0) {
     on = g_prof.open && g_prof.stream == stream;
     if (!on) return;
     rec.cls = cls;
     rec.bytes = bytes;
+    rec.streaming = streaming;
     rec.hbm_bytes = hbm_bytes < 0 ? bytes : hbm_bytes;
     rec.e0 = prof_event();
     rec.e1 = prof_event();
@@ -235,7 +239,7 @@ static int launch_reg(const Plan& p, hipStream_t stream) {
   for (int i = 0; i < NM * NM; ++i) a.u[i] = p.u[i];
   const u64 per_block = (u64)kBlock * ITEMS;
   const u64 blocks = (p.count + per_block - 1) / per_block;
-  ProfileScope prof(NM == 1 ? 0 : (NM == 2 ? 1 : 2), 32.0 * NM * (double)p.count, stream);
+  ProfileScope prof(NM == 1 ? 0 : (NM == 2 ? 1 : 2), 32.0 * NM * (double)p.count, stream, NT);
   hipLaunchKernelGGL((k_gate<NM, ITEMS, NT, SWZ>), grid_for(blocks), dim3(kBlock), 0, stream, a);
   prof.done(stream);
   HIP_TRY(hipGetLastError());
@@ -255,7 +259,7 @@ static int launch_shuffle(const Plan& p, hipStream_t stream) {
   for (int i = 0; i < DIM * DIM; ++i) a.u[i] = p.u[i];
   const u64 per_block = (u64)kBlock * ITEMS;
   const u64 blocks = (p.count + per_block - 1) / per_block;
-  ProfileScope prof(NMR == 2 ? 5 : (NSH == 1 ? 3 : 4), 32.0 * NMR * (double)p.count, stream);
+  ProfileScope prof(NMR == 2 ? 5 : (NSH == 1 ? 3 : 4), 32.0 * NMR * (double)p.count, stream, NT);
   hipLaunchKernelGGL((k_gate_shuffle<NMR, NSH, ITEMS, NT>), grid_for(blocks), dim3(kBlock), 0, stream, a);
   prof.done(stream);
   HIP_TRY(hipGetLastError());

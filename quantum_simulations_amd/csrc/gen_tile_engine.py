@@ -51,6 +51,9 @@ NOBARRIER = os.environ.get("QS_GEN_NOBARRIER", "0") == "1"
 # PROBE ONLY: extra instructions per record in the fetch + dispatch sequence, e.g. QS_GEN_PAD="s_nop 0*4"
 PAD = os.environ.get("QS_GEN_PAD", "")
 PAD_AFTER = os.environ.get("QS_GEN_PAD_AFTER", "")      # ... the same after the wait for the record
+# A/B: QS_GEN_SWAP=mov64 exchanges amplitude registers with v_mov_b64 through the f64 temporaries (6 full-rate moves
+# per pair of amplitudes) instead of 4 v_swap_b32 (half rate)
+SWAP_MOV64 = os.environ.get("QS_GEN_SWAP", "") == "mov64"
 
 
 # ---- entry numbers (header dword 0 = 4 * entry); the gate families keep the r01 opcode numbers ----
@@ -234,6 +237,21 @@ def body_anti(a, bank, pairs):
 
 
 def body_swap(a, bank, pairs):
+    if SWAP_MOV64:
+        for i, (pa, pb) in enumerate(pairs):
+            ax, ay, _ = X(pa)
+            a(f"v_mov_b64 {T(2 * i)}, {ax}")
+            a(f"v_mov_b64 {T(2 * i + 1)}, {ay}")
+        for pa, pb in pairs:
+            ax, ay, _ = X(pa)
+            bx, by, _ = X(pb)
+            a(f"v_mov_b64 {ax}, {bx}")
+            a(f"v_mov_b64 {ay}, {by}")
+        for i, (pa, pb) in enumerate(pairs):
+            bx, by, _ = X(pb)
+            a(f"v_mov_b64 {bx}, {T(2 * i)}")
+            a(f"v_mov_b64 {by}, {T(2 * i + 1)}")
+        return
     for pa, pb in pairs:
         for c in range(4):
             a(f"v_swap_b32 {XD(pa, c)}, {XD(pb, c)}")

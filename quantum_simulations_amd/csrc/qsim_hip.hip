@@ -776,12 +776,13 @@ int qsim_profile_end(qsim_chunk* c, int max_entries, int* n_entries, qsim_profil
   g_prof.open = false;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  uint64_t launches[kNumClasses] = {0};
+  uint64_t launches[kNumClasses] = {0}, streaming[kNumClasses] = {0};
   double ms[kNumClasses] = {0}, bytes[kNumClasses] = {0}, hbm[kNumClasses] = {0};
   for (LaunchRecord& r : g_prof.records) {
     float t = 0.f;
     HIP_TRY(hipEventElapsedTime(&t, r.e0, r.e1));
     launches[r.cls] += 1;
+    streaming[r.cls] += r.streaming ? 1 : 0;
     ms[r.cls] += t;
     bytes[r.cls] += r.bytes;
     hbm[r.cls] += r.hbm_bytes;
@@ -798,6 +799,7 @@ int qsim_profile_end(qsim_chunk* c, int max_entries, int* n_entries, qsim_profil
       out[n].total_ms = ms[cls];
       out[n].algorithmic_bytes = bytes[cls];
       out[n].hbm_bytes = hbm[cls];
+      out[n].streaming_launches = streaming[cls];
     }
     ++n;
   }

@@ -135,9 +135,9 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   // all are < 28
   bool wide = false;
   for (int i = 0; i < kTileThreadBits - kTileLow && i < T - kTileLow; ++i) wide = wide || a.lay_in[i] >= 28 || a.lay_out[i] >= 28;
-  ProfileScope prof(6, alg_bytes, stream, 32.0 * (double)amps(c));
   bool nt = c->span_bytes > tuning().mall_bytes;       // cache policy by state size (gate_plan.h)
   if (tuning().force_nt >= 0) nt = tuning().force_nt != 0;
+  ProfileScope prof(6, alg_bytes, stream, nt, 32.0 * (double)amps(c));
   // Two tiles per workgroup, the second one's loads in flight while the first is computed on
   // (profiles/r02r_ab_prefetch_before_engine.txt: -3.9 % per pass; 4 or 8 tiles per workgroup lose it again,
   // profiles/r02z_ab_paired_stores.txt).  Also for the 64-bit-offset form (110 VGPRs: the 32 KiB of LDS admit four
@@ -952,6 +952,23 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
 #endif
     int rc = serialize_pass(groups, &a);
     if (rc) return rc;
+#ifdef QSIM_PROBES
+    // Engine-floor probe (WRONG results): QSIM_DEBUG_REMAP_TILE="b0,...,b7" keeps the pass's record stream but moves
+    // its tile to these index bits (j-th smallest tile bit -> j-th listed bit), i.e. the same gates on another
+    // memory pattern: what would the pass cost if its tile always had the fastest layout?
+    if (const char* e = getenv("QSIM_DEBUG_REMAP_TILE")) {
+      std::vector<int> bits;
+      for (const char* q = e; *q;) { bits.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; }
+      if ((int)bits.size() == cap && T == kTileBitsMax) {
+        std::sort(bits.begin(), bits.end());
+        uint8_t map[64];
+        for (int b = 0; b < 64; ++b) map[b] = (uint8_t)b;
+        for (int j = 0; j < cap; ++j) map[a.h[j]] = (uint8_t)bits[(size_t)j];
+        for (int j = 0; j < cap; ++j) { a.lay_in[j] = map[a.lay_in[j]]; a.lay_out[j] = map[a.lay_out[j]]; }
+        for (int j = 0; j < cap; ++j) a.h[j] = (uint8_t)bits[(size_t)j];
+      }
+    }
+#endif
     if (tune.debug_stats) {
       size_t descs = 0;
       for (const TileGroup& g : groups) descs += g.gates.size();

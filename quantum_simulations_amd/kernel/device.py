@@ -185,7 +185,7 @@ class DeviceChunk:
         for e in entries[: min(n.value, 16)]:
             out.append({"kernel": e.kernel.decode(), "launches": int(e.launches),
                         "total_ms": float(e.total_ms), "algorithmic_bytes": float(e.algorithmic_bytes),
-                        "hbm_bytes": float(e.hbm_bytes)})
+                        "hbm_bytes": float(e.hbm_bytes), "streaming_launches": int(e.streaming_launches)})
         return out
 
     def pack_half(self, bit: int, value: int, buf: "DeviceChunk") -> None:

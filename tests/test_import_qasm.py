@@ -147,3 +147,28 @@ def test_qasmbench_inputs_of_the_reference_when_present():
             rejected.append(path.parent.name)
     assert len(ok) >= 25, (ok, rejected)
     assert {"qft_n20", "adder_n28", "bv_n30", "grover_n30", "cat_state_n30"} <= {name for name, _, _ in ok}
+
+
+def test_generated_family_texts_and_their_closed_forms():
+    """tests/qasm_texts.py (the texts tests/test_gpu_qasm.py takes through the HIP path) at sizes numpy finishes
+    instantly: dense_oracle.py == the C restatement, and each family's closed-form answer holds."""
+    from oracle import c_oracle
+    from tests.qasm_texts import bernstein_vazirani, phase_estimation, qft_cu1, ripple_adder
+
+    def run(src):
+        cd = validate_circuit_dict(qasm_to_dict(src))
+        psi = orc.simulate(cd)
+        np.testing.assert_allclose(c_oracle.simulate(cd), psi, rtol=0, atol=1e-13)
+        return psi
+
+    psi = run(bernstein_vazirani(6, 0b10110))
+    assert abs(abs(psi[0b10110]) - 2 ** -0.5) < 1e-12 and abs(abs(psi[0b10110 | 32]) - 2 ** -0.5) < 1e-12
+    for bits, a, b in ((2, 3, 1), (3, 5, 7), (4, 9, 15)):
+        psi = run(ripple_adder(bits, a, b))
+        total = a + b
+        index = (a << 1) | ((total & ((1 << bits) - 1)) << (bits + 1)) | ((total >> bits) << (2 * bits + 1))
+        assert abs(abs(psi[index]) - 1) < 1e-12, (bits, a, b, int(np.argmax(np.abs(psi))), index)
+    np.testing.assert_allclose(np.abs(run(qft_cu1(5, 9))), 2 ** -2.5, atol=1e-13)
+    for t, num in ((4, 11), (5, 1), (6, 42)):
+        psi = run(phase_estimation(t, num))
+        assert abs(abs(psi[num | (1 << t)]) - 1) < 1e-12, (t, num, int(np.argmax(np.abs(psi))))

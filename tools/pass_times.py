@@ -6,6 +6,8 @@ import sys
 from pathlib import Path
 
 os.environ["QSIM_DEBUG_STATS"] = "2"
+# (knobs exist in the probe build only)
+os.environ.setdefault("QSIM_LIBRARY", str(Path(__file__).resolve().parent.parent / "quantum_simulations_amd" / "libqsim_hip_probes.so"))
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from quantum_simulations_amd.circuits import random_1q_cx_circuit  # noqa: E402
 from quantum_simulations_amd.runner.engine import make_engine  # noqa: E402

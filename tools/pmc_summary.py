@@ -20,6 +20,8 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from quantum_simulations_amd._lib import source_hash  # noqa: E402
 
 
 def klass(name: str):
@@ -70,7 +72,7 @@ def main():
             row["write_size_KiB_avg"] = ws[k][1]
             row["hbm_bytes_per_launch"] = (2.0 * fs[k][1] + ws[k][1]) * 1024.0
         rows.append(row)
-    doc = {"tag": tag, "source": "rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE "
+    doc = {"tag": tag, "csrc_sha16": source_hash(), "source": "rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE "
                                  "(separate passes) on `python3 bench.py`",
            "correction": "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE = 1/2 of "
                          "wide coalesced reads; WRITE_SIZE exact for 16-B streaming stores)",
