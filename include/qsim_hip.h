@@ -82,6 +82,27 @@ int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* q
 int qsim_apply_ops_unfused(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits,
                            const double* mats);
 int qsim_last_pass_count(const qsim_chunk* c);
+
+/* ---- op list with a re-layout fused into its ends ------------------------------------------------
+ * Multi-GPU re-layouts (the staging SWAP lists of wenbo_engine/circuit/staging.py:136-152, merged into one
+ * all-to-all) move the shard through exchange buffers in SLAB layout (qsim_pack_all below).  Instead of one extra
+ * HBM pass before the exchange (pack) and one after it (unpack), the last fused pass of the op list BEFORE the
+ * exchange stores its tiles straight into the send buffer in slab order, and the first pass of the op list AFTER it
+ * loads them from the receive buffer: same arithmetic as qsim_apply_ops on the chunk, two passes fewer.
+ *   src  != NULL: the state is read from `src`, which holds it in the slab layout over src_bits (qsim_pack_all
+ *                 with skip_pattern -1); the chunk's own contents are ignored and overwritten.
+ *   dst  != NULL: after the ops the state is left in `dst` in the slab layout over dst_bits -- except slab
+ *                 own_pattern (>= 0), which is left at its place in `dst_own` (the receive buffer: that slab stays
+ *                 on this rank); the chunk's own contents are unspecified afterwards.
+ * Parts that cannot be fused (a slab bit inside a 128-byte line, fewer qubits than a tile holds, no ops, a slab bit
+ * among the tile bits of the last pass) run as separate slab passes; *n_passes reports the HBM passes made. */
+typedef struct {
+  const qsim_chunk* src; int32_t src_m; int32_t src_bits[3];
+  qsim_chunk* dst; int32_t dst_m; int32_t dst_bits[3];
+  qsim_chunk* dst_own; int32_t own_pattern;
+} qsim_ops_io;
+int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits,
+                      const double* mats, const qsim_ops_io* io, int* n_passes);
 /* The host planner of the fused passes WITHOUT a device (used by the CPU tests): plans the op list
  * for a 2^n_local_qubits chunk and writes one QSIM_PASS_IMAGE_BYTES pass image per planned pass to `out`
  * (layout = the kernel-argument block of k_tile, csrc/tile_kernel.h: record count, tile size T, tile high
@@ -144,6 +165,7 @@ int qsim_comm_rank(const qsim_comm* comm);
 int qsim_comm_world(const qsim_comm* comm);
 /* One grouped exchange: for every i < n_peers send `count_amps` amplitudes of `send` starting at
  * send_off[i] to rank peers[i] and receive as many from it into `recv` at recv_off[i].            */
+/* (send and recv must be chunks on the SAME stream: the transfer is ordered on it) */
 int qsim_comm_exchange(qsim_comm* comm, int n_peers, const int32_t* peers, const qsim_chunk* send,
                        const uint64_t* send_off, qsim_chunk* recv, const uint64_t* recv_off, uint64_t count_amps);
 /* qsim_swap_global_local ACROSS GPUs: local qubit local_bits[i] of this rank's shard trades places
@@ -154,6 +176,21 @@ int qsim_comm_exchange(qsim_comm* comm, int n_peers, const int32_t* peers, const
  * (1 - 2^-m) of a shard crosses the links per rank.                                                */
 int qsim_comm_relayout(qsim_comm* comm, qsim_chunk* state, qsim_chunk* buf0, qsim_chunk* buf1, int m,
                        const int32_t* local_bits, const int32_t* global_bits, int n_pieces);
+/* The schedule of qsim_comm_relayout as a pure function (no GPU, no communicator): for rank `rank` of `world` it
+ * returns the pieces really used (pieces keep >= 2^20 amplitudes), this rank's own pattern (the slab that stays), and
+ * per peer its rank and the amplitude offset of its slab in the send AND the receive buffer; piece s of a slab is
+ * [offset + s * piece_amps, + piece_amps).  Output arrays hold up to 7 entries.  The pairing is that of the
+ * reference's partner groups (wenbo_engine/runner/single_node.py:222-245) with one chunk per rank. */
+int qsim_comm_relayout_plan(int rank, int world, int n_local_qubits, int m, const int32_t* local_bits,
+                            const int32_t* global_bits, int n_pieces, int32_t* out_n_pieces, int32_t* out_n_peers,
+                            int32_t* out_own_pattern, int32_t* out_peers, uint64_t* out_slab_offsets,
+                            uint64_t* out_piece_amps);
+/* The same pipeline (packs, events, second stream, RCCL groups, unpacks) as rank `as_rank` of `as_world` would run
+ * it, every transfer looped back to this rank: runnable on ONE GPU; the state is unchanged afterwards and buf1 holds
+ * the slabs that were "received". */
+int qsim_comm_relayout_loopback(qsim_comm* comm, qsim_chunk* state, qsim_chunk* buf0, qsim_chunk* buf1, int m,
+                                const int32_t* local_bits, const int32_t* global_bits, int n_pieces, int as_rank,
+                                int as_world);
 /* cpu_nonlocal.apply_1q_pair / apply_2q_pair_qa_local / apply_2q_pair_qb_local (cpu_nonlocal.py:22-58)
  * with the partner chunk on rank `partner_rank` (both ranks call, naming each other): the partner's
  * shard is received into `buf` and this rank's shard is updated.  my_side = this rank's value of the

@@ -14,7 +14,21 @@
 // RCCL is resolved with dlopen at the first qsim_comm_* call (no link-time dependency: a process that has
 // torch's bundled librccl loaded shares it; a plain C host gets /opt/rocm/lib/librccl.so.1).
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// A host without the RCCL development headers still builds the library (RCCL is only ever dlopen'ed): the few
+// types and constants of the NCCL API that the calls below use.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5,
+               ncclFloat16 = 6, ncclFloat32 = 7, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+}
+#endif
+static_assert(ncclDouble == 8 && ncclSuccess == 0 && NCCL_UNIQUE_ID_BYTES == 128, "NCCL ABI constants");
 
 struct RcclApi {
   void* lib = nullptr;
@@ -73,7 +87,9 @@ static int check_comm(const qsim_comm* c, const char* what) {
   return QSIM_OK;
 }
 
-// grouped exchange of [off, off + count) amplitude slices with each peer, on `stream`
+// grouped exchange of [off, off + count) amplitude slices with each peer, on `stream`.  Ordering: the transfer is
+// queued on `stream` only -- the caller must have BOTH buffers' producers / consumers on that stream (qsim_comm_exchange
+// checks that the send and the receive chunk share it).
 static int comm_exchange(qsim_comm* cm, int n_peers, const int32_t* peers, const double2* send, const uint64_t* send_off,
                          double2* recv, const uint64_t* recv_off, uint64_t count, hipStream_t stream) {
   RCCL_TRY(g_rccl.GroupStart());

@@ -309,7 +309,7 @@ int qsim_plan_ops(int n_local_qubits, int n_ops, const int32_t* nq, const int32_
   int passes = 0;
   char* dst = (char*)out;
   uint64_t used = 0;
-  int rc = plan_fused(n_local_qubits, ops, &passes, [&](TileArgs& a, int T, double) {
+  int rc = plan_fused(n_local_qubits, ops, &passes, [&](TileArgs& a, int T, double, bool, bool) {
     if (dst) {
       if (used + sizeof(TileArgs) > out_capacity_bytes) return fail(QSIM_ERR_INVALID, "qsim_plan_ops: output buffer too small");
       std::memcpy(dst + used, &a, sizeof a);
@@ -531,6 +531,86 @@ int qsim_swap_global_local(qsim_chunk* const* chunks, int n_chunks, const int32_
   return QSIM_OK;
 }
 
+// Op list with a re-layout fused into its ends (staging.py:136-152 SWAP lists): the FIRST fused pass reads
+// the state from io->src in the slab layout of qsim_pack_all over io->src_bits (what an all-to-all left in the receive
+// buffer) instead of a separate unpack pass, the LAST one stores it into io->dst in the slab layout over io->dst_bits
+// (slab io->own_pattern, which stays on this rank, into io->dst_own) instead of a separate pack pass.  Whatever cannot
+// be fused (bits inside a 128-B line, chunks too small for tile passes, an empty op list, a slab bit that is a tile
+// bit of the last pass) is done with the slab kernels, so the result is the same in every case; *n_passes counts the
+// HBM passes really made.
+int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,
+                      const qsim_ops_io* io, int* n_passes) {
+  int rc = validate_ops(c, n_ops, nq, qubits, mats);
+  if (rc) return rc;
+  if (!io) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: io is null");
+  auto check_side = [&](const qsim_chunk* b, int m, const int32_t* bits, const char* side) -> int {
+    int r = check_chunk(b, "qsim_apply_ops_io");
+    if (r) return r;
+    if (b->k != c->k || b->device != c->device || b->amp == c->amp)
+      return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: the %s buffer must be a distinct chunk of the state's size and device", side);
+    if (m < 1 || m > 3 || m > c->k) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: %s: 1..3 slab bits expected, got %d", side, m);
+    for (int i = 0; i < m; ++i) {
+      if (bits[i] < 0 || bits[i] >= c->k) return fail(QSIM_ERR_NONLOCAL, "qsim_apply_ops_io: %s slab bit %d is non-local for 2^%d amplitudes", side, bits[i], c->k);
+      for (int j = 0; j < i; ++j) if (bits[j] == bits[i]) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: %s: repeated slab bit %d", side, bits[i]);
+    }
+    return QSIM_OK;
+  };
+  if (io->src && (rc = check_side(io->src, io->src_m, io->src_bits, "source"))) return rc;
+  if (io->dst) {
+    if ((rc = check_side(io->dst, io->dst_m, io->dst_bits, "destination"))) return rc;
+    if (io->own_pattern < -1 || io->own_pattern >= (1 << io->dst_m)) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: own_pattern out of range");
+    if (io->own_pattern >= 0 && (rc = check_side(io->dst_own, io->dst_m, io->dst_bits, "own-slab"))) return rc;
+    if (io->own_pattern >= 0 && io->dst_own->amp == io->dst->amp) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: the own-slab buffer must differ from the destination");
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  std::vector<FusedOp> ops;
+  ops.reserve((size_t)n_ops);
+  for (int i = 0; i < n_ops; ++i) {
+    FusedOp o;
+    if (classify_op(nq[i], qubits + 2 * i, mats + 32 * (size_t)i, &o)) ops.push_back(o);
+  }
+  const bool tiles = c->k >= kTileMinChunk && c->k <= kTileMaxQubits && !ops.empty();
+  auto whole_lines = [](int m, const int32_t* bits) { for (int i = 0; i < m; ++i) if (bits[i] < kTileLow) return false; return true; };
+  FusedIo fio;
+  if (io->src && tiles && whole_lines(io->src_m, io->src_bits)) {
+    fio.src = io->src;
+    fio.in.m = io->src_m;
+    for (int i = 0; i < io->src_m; ++i) fio.in.bits[i] = io->src_bits[i];
+  }
+  if (io->dst && tiles && whole_lines(io->dst_m, io->dst_bits)) {
+    fio.dst = io->dst;
+    fio.dst_own = io->dst_own;
+    fio.own_pattern = io->own_pattern;
+    fio.out.m = io->dst_m;
+    for (int i = 0; i < io->dst_m; ++i) fio.out.bits[i] = io->dst_bits[i];
+  }
+  int passes = 0;
+  if (io->src && !fio.src) {           // not fusable: one unpack pass brings the state into the chunk
+    if ((rc = slabs_all(c, io->src_m, io->src_bits, const_cast<qsim_chunk*>(io->src), -1, 0, 1, false, "qsim_apply_ops_io"))) return rc;
+    ++passes;
+  }
+  if (tiles) {
+    int p = 0;
+    if ((rc = run_fused(c, ops, &p, &fio))) return rc;
+    passes += p;
+    if (fio.src && !fio.fused_in) return fail(QSIM_ERR_INVALID, "internal: the first pass did not take the source buffer");
+  } else {
+    if ((rc = qsim_apply_ops_unfused(c, n_ops, nq, qubits, mats))) return rc;
+    passes += n_ops;
+  }
+  if (io->dst && !fio.fused_out) {     // not fused: pack passes
+    if ((rc = slabs_all(c, io->dst_m, io->dst_bits, io->dst, io->own_pattern, 0, 1, true, "qsim_apply_ops_io"))) return rc;
+    ++passes;
+    if (io->own_pattern >= 0) {
+      const uint64_t slab = 1ull << (c->k - io->dst_m);
+      if ((rc = qsim_pack_bits(c, io->dst_m, io->dst_bits, io->own_pattern, io->dst_own, (uint64_t)io->own_pattern * slab))) return rc;
+    }
+  }
+  c->last_passes = passes;
+  if (n_passes) *n_passes = passes;
+  return QSIM_OK;
+}
+
 // ---- multi-GPU reach of the C ABI (comm_rccl.h) ---------------------------------------------------
 int qsim_comm_get_unique_id(uint8_t id[QSIM_COMM_ID_BYTES]) {
   static_assert(QSIM_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
@@ -581,6 +661,7 @@ int qsim_comm_exchange(qsim_comm* cm, int n_peers, const int32_t* peers, const q
   if (rc || (rc = check_chunk(send, "qsim_comm_exchange")) || (rc = check_chunk(recv, "qsim_comm_exchange"))) return rc;
   if (n_peers < 0 || (n_peers && (!peers || !send_off || !recv_off))) return fail(QSIM_ERR_INVALID, "qsim_comm_exchange: bad peer list");
   if (send->amp == recv->amp) return fail(QSIM_ERR_INVALID, "qsim_comm_exchange: send and receive chunks must differ");
+  if (send->stream != recv->stream) return fail(QSIM_ERR_INVALID, "qsim_comm_exchange: the send and the receive chunk must share a stream (the transfer is ordered on it)");
   for (int i = 0; i < n_peers; ++i) {
     if (peers[i] < 0 || peers[i] >= cm->world) return fail(QSIM_ERR_INVALID, "qsim_comm_exchange: peer %d out of range", peers[i]);
     if (send_off[i] > amps(send) || count_amps > amps(send) - send_off[i] || recv_off[i] > amps(recv) || count_amps > amps(recv) - recv_off[i])
@@ -590,6 +671,97 @@ int qsim_comm_exchange(qsim_comm* cm, int n_peers, const int32_t* peers, const q
   return comm_exchange(cm, n_peers, peers, send->amp, send_off, recv->amp, recv_off, count_amps, send->stream);
 }
 
+// ---- all-to-all re-layout: ONE schedule, computed by a pure function --------------------------------------------
+// Who sends what to whom when rank `rank` of `world` swaps its local bits local_bits[i] with the rank bits
+// global_bits[i] (bit g of the rank = qubit k + g): the partner semantics of the reference's chunk groups
+// (wenbo_engine/runner/single_node.py:222-245) with one chunk per rank.  Slab d of the send buffer (offset d * 2^(k-m):
+// this rank's amplitudes whose local bits have the pattern d) goes to the rank whose global-bit pattern is d, and that
+// rank's slab `own` (own = this rank's pattern) arrives at the same offset d of the receive buffer; the own slab stays.
+// Pieces: every slab is cut into n_pieces equal parts that travel one after the other (pack / transfer / unpack overlap).
+struct RelayoutPlan {
+  int n_pieces, n_peers, own;
+  int32_t peers[7];
+  uint64_t offs[7];          // amplitude offset of the peer's slab in the send AND the receive buffer
+  uint64_t slab, part;       // amplitudes per slab / per piece
+};
+static int relayout_plan(int rank, int world, int k, int m, const int32_t* local_bits, const int32_t* global_bits,
+                         int n_pieces, RelayoutPlan* p) {
+  if (world < 1 || (world & (world - 1)) || rank < 0 || rank >= world) return fail(QSIM_ERR_INVALID, "re-layout: bad rank %d / world %d", rank, world);
+  if (m < 1 || m > 3 || !local_bits || !global_bits) return fail(QSIM_ERR_INVALID, "re-layout: 1..3 qubit pairs expected, got %d", m);
+  int g_bits = 0;
+  while ((1 << g_bits) < world) ++g_bits;
+  for (int i = 0; i < m; ++i) {
+    if (local_bits[i] < 0 || local_bits[i] >= k) return fail(QSIM_ERR_NONLOCAL, "re-layout: local bit %d is non-local for 2^%d shards", local_bits[i], k);
+    if (global_bits[i] < 0 || global_bits[i] >= g_bits) return fail(QSIM_ERR_INVALID, "re-layout: rank bit %d out of range", global_bits[i]);
+    for (int j = 0; j < i; ++j)
+      if (local_bits[j] == local_bits[i] || global_bits[j] == global_bits[i]) return fail(QSIM_ERR_INVALID, "re-layout: repeated bit");
+  }
+  if (n_pieces != 1 && n_pieces != 2 && n_pieces != 4 && n_pieces != 8) return fail(QSIM_ERR_INVALID, "re-layout: n_pieces must be 1, 2, 4 or 8");
+  while (n_pieces > 1 && (k - m) - (31 - __builtin_clz((unsigned)n_pieces)) < 20) n_pieces >>= 1;   // pieces stay >= 2^20 amplitudes
+  if (k - m < 3) n_pieces = 1;
+  p->n_pieces = n_pieces;
+  p->own = 0;
+  for (int i = 0; i < m; ++i) p->own |= ((rank >> global_bits[i]) & 1) << i;
+  p->slab = 1ull << (k - m);
+  p->part = p->slab / (u64)n_pieces;
+  p->n_peers = 0;
+  for (int d = 0; d < (1 << m); ++d) {
+    if (d == p->own) continue;
+    int peer = rank;
+    for (int i = 0; i < m; ++i) peer = (peer & ~(1 << global_bits[i])) | (((d >> i) & 1) << global_bits[i]);
+    p->peers[p->n_peers] = peer;
+    p->offs[p->n_peers] = (u64)d * p->slab;
+    ++p->n_peers;
+  }
+  return QSIM_OK;
+}
+
+int qsim_comm_relayout_plan(int rank, int world, int n_local_qubits, int m, const int32_t* local_bits, const int32_t* global_bits,
+                            int n_pieces, int32_t* out_n_pieces, int32_t* out_n_peers, int32_t* out_own_pattern,
+                            int32_t* out_peers, uint64_t* out_slab_offsets, uint64_t* out_piece_amps) {
+  RelayoutPlan p;
+  int rc = relayout_plan(rank, world, n_local_qubits, m, local_bits, global_bits, n_pieces, &p);
+  if (rc) return rc;
+  if (out_n_pieces) *out_n_pieces = p.n_pieces;
+  if (out_n_peers) *out_n_peers = p.n_peers;
+  if (out_own_pattern) *out_own_pattern = p.own;
+  for (int i = 0; i < p.n_peers; ++i) {
+    if (out_peers) out_peers[i] = p.peers[i];
+    if (out_slab_offsets) out_slab_offsets[i] = p.offs[i];
+  }
+  if (out_piece_amps) *out_piece_amps = p.part;
+  return QSIM_OK;
+}
+
+// pipeline: pack piece s+1 (chunk stream) while piece s is on the links (transfer stream); unpack behind it.
+// loopback: every peer is this rank itself (the slabs come back unchanged): the same packs, events, streams, RCCL
+// groups and unpacks as a real re-layout of the planned rank, runnable on one GPU.
+static int relayout_run(qsim_comm* cm, qsim_chunk* state, qsim_chunk* buf0, qsim_chunk* buf1, int m, const int32_t* local_bits,
+                        const RelayoutPlan& p, bool loopback) {
+  int rc = QSIM_OK;
+  if (buf0->k != state->k || buf1->k != state->k || buf0->amp == buf1->amp || buf0->amp == state->amp || buf1->amp == state->amp)
+    return fail(QSIM_ERR_INVALID, "re-layout: two distinct exchange buffers of the shard's size are needed");
+  HIP_TRY(hipSetDevice(cm->device));
+  if (!cm->xfer_stream) HIP_TRY(hipStreamCreateWithFlags(&cm->xfer_stream, hipStreamNonBlocking));
+  for (auto& e : cm->ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  int32_t peers[7];
+  for (int i = 0; i < p.n_peers; ++i) peers[i] = loopback ? cm->rank : p.peers[i];
+  for (int s = 0; s < p.n_pieces; ++s) {
+    if ((rc = slabs_all(state, m, local_bits, buf0, p.own, s, p.n_pieces, true, "qsim_comm_relayout"))) return rc;
+    HIP_TRY(hipEventRecord(cm->ev[2 * s], state->stream));
+    HIP_TRY(hipStreamWaitEvent(cm->xfer_stream, cm->ev[2 * s], 0));
+    uint64_t so[7];
+    for (int i = 0; i < p.n_peers; ++i) so[i] = p.offs[i] + (u64)s * p.part;
+    if ((rc = comm_exchange(cm, p.n_peers, peers, buf0->amp, so, buf1->amp, so, p.part, cm->xfer_stream))) return rc;
+    HIP_TRY(hipEventRecord(cm->ev[2 * s + 1], cm->xfer_stream));
+  }
+  for (int s = 0; s < p.n_pieces; ++s) {
+    HIP_TRY(hipStreamWaitEvent(state->stream, cm->ev[2 * s + 1], 0));
+    if ((rc = slabs_all(state, m, local_bits, buf1, p.own, s, p.n_pieces, false, "qsim_comm_relayout"))) return rc;
+  }
+  return QSIM_OK;
+}
+
 // All-to-all re-layout of THIS rank's shard: local bits `local_bits[i]` trade places with rank bits
 // `global_bits[i]` (bit g of the rank = qubit k + g).  buf0 / buf1: exchange buffers of the shard's size.
 int qsim_comm_relayout(qsim_comm* cm, qsim_chunk* state, qsim_chunk* buf0, qsim_chunk* buf1, int m,
@@ -597,54 +769,21 @@ int qsim_comm_relayout(qsim_comm* cm, qsim_chunk* state, qsim_chunk* buf0, qsim_
   int rc = check_comm(cm, "qsim_comm_relayout");
   if (rc || (rc = check_chunk(state, "qsim_comm_relayout")) || (rc = check_chunk(buf0, "qsim_comm_relayout")) ||
       (rc = check_chunk(buf1, "qsim_comm_relayout"))) return rc;
-  if (m < 1 || m > 3 || !local_bits || !global_bits) return fail(QSIM_ERR_INVALID, "qsim_comm_relayout: 1..3 qubit pairs expected, got %d", m);
-  if (buf0->k != state->k || buf1->k != state->k || buf0->amp == buf1->amp || buf0->amp == state->amp || buf1->amp == state->amp)
-    return fail(QSIM_ERR_INVALID, "qsim_comm_relayout: two distinct exchange buffers of the shard's size are needed");
-  int g_bits = 0;
-  while ((1 << g_bits) < cm->world) ++g_bits;
-  for (int i = 0; i < m; ++i) {
-    if (local_bits[i] < 0 || local_bits[i] >= state->k)
-      return fail(QSIM_ERR_NONLOCAL, "qsim_comm_relayout: local bit %d is non-local for 2^%d shards", local_bits[i], state->k);
-    if (global_bits[i] < 0 || global_bits[i] >= g_bits) return fail(QSIM_ERR_INVALID, "qsim_comm_relayout: rank bit %d out of range", global_bits[i]);
-    for (int j = 0; j < i; ++j)
-      if (local_bits[j] == local_bits[i] || global_bits[j] == global_bits[i]) return fail(QSIM_ERR_INVALID, "qsim_comm_relayout: repeated bit");
-  }
-  if (n_pieces != 1 && n_pieces != 2 && n_pieces != 4 && n_pieces != 8) return fail(QSIM_ERR_INVALID, "qsim_comm_relayout: n_pieces must be 1, 2, 4 or 8");
-  while (n_pieces > 1 && (state->k - m) - (31 - __builtin_clz((unsigned)n_pieces)) < 20) n_pieces >>= 1;   // pieces stay >= 2^20 amplitudes
-  if (state->k - m < 3) n_pieces = 1;
-  HIP_TRY(hipSetDevice(cm->device));
-  if (!cm->xfer_stream) HIP_TRY(hipStreamCreateWithFlags(&cm->xfer_stream, hipStreamNonBlocking));
-  for (auto& e : cm->ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  int mine = 0;
-  for (int i = 0; i < m; ++i) mine |= ((cm->rank >> global_bits[i]) & 1) << i;
-  int32_t peers[7];
-  uint64_t offs[7];
-  const u64 slab = 1ull << (state->k - m);
-  const u64 part = slab / (u64)n_pieces;
-  int n_peers = 0;
-  for (int d = 0; d < (1 << m); ++d) {
-    if (d == mine) continue;
-    int peer = cm->rank;
-    for (int i = 0; i < m; ++i) peer = (peer & ~(1 << global_bits[i])) | (((d >> i) & 1) << global_bits[i]);
-    peers[n_peers] = peer;
-    offs[n_peers] = (u64)d * slab;              // slab d of the send buffer goes to the rank whose pattern is d
-    ++n_peers;
-  }
-  // pipeline: pack piece s+1 (main stream) while piece s is on the links (transfer stream); unpack behind it
-  for (int s = 0; s < n_pieces; ++s) {
-    if ((rc = slabs_all(state, m, local_bits, buf0, mine, s, n_pieces, true, "qsim_comm_relayout"))) return rc;
-    HIP_TRY(hipEventRecord(cm->ev[2 * s], state->stream));
-    HIP_TRY(hipStreamWaitEvent(cm->xfer_stream, cm->ev[2 * s], 0));
-    uint64_t so[7];
-    for (int i = 0; i < n_peers; ++i) so[i] = offs[i] + (u64)s * part;
-    if ((rc = comm_exchange(cm, n_peers, peers, buf0->amp, so, buf1->amp, so, part, cm->xfer_stream))) return rc;
-    HIP_TRY(hipEventRecord(cm->ev[2 * s + 1], cm->xfer_stream));
-  }
-  for (int s = 0; s < n_pieces; ++s) {
-    HIP_TRY(hipStreamWaitEvent(state->stream, cm->ev[2 * s + 1], 0));
-    if ((rc = slabs_all(state, m, local_bits, buf1, mine, s, n_pieces, false, "qsim_comm_relayout"))) return rc;
-  }
-  return QSIM_OK;
+  RelayoutPlan p;
+  if ((rc = relayout_plan(cm->rank, cm->world, state->k, m, local_bits, global_bits, n_pieces, &p))) return rc;
+  return relayout_run(cm, state, buf0, buf1, m, local_bits, p, false);
+}
+
+// The pipeline of qsim_comm_relayout as rank `as_rank` of a world of `as_world` would run it, with every transfer
+// looped back to this rank: the state is unchanged afterwards and buf1 holds the slabs that were "received".
+int qsim_comm_relayout_loopback(qsim_comm* cm, qsim_chunk* state, qsim_chunk* buf0, qsim_chunk* buf1, int m,
+                                const int32_t* local_bits, const int32_t* global_bits, int n_pieces, int as_rank, int as_world) {
+  int rc = check_comm(cm, "qsim_comm_relayout_loopback");
+  if (rc || (rc = check_chunk(state, "qsim_comm_relayout_loopback")) || (rc = check_chunk(buf0, "qsim_comm_relayout_loopback")) ||
+      (rc = check_chunk(buf1, "qsim_comm_relayout_loopback"))) return rc;
+  RelayoutPlan p;
+  if ((rc = relayout_plan(as_rank, as_world, state->k, m, local_bits, global_bits, n_pieces, &p))) return rc;
+  return relayout_run(cm, state, buf0, buf1, m, local_bits, p, true);
 }
 
 // The reference's partner-chunk butterflies with the partner chunk on ANOTHER rank: both ranks call with each

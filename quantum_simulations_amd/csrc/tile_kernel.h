@@ -85,15 +85,23 @@ static inline int opc_1q_variant(int J, int C) {
 //           d5..d11 = LDS byte-address XOR constants of registers x1..x7 (lds_slot is linear over GF(2))
 //   end:    d0 = 4 x OPC_END(_DIRECT), d1 = its own offset
 constexpr int kTileArgBytes = 4096;
-constexpr int kTileStreamOff = 64;                       // byte offset of the first record
+constexpr int kTileStreamOff = 192;                      // byte offset of the first record
 constexpr int kTileStreamBytes = kTileArgBytes - kTileStreamOff;
 constexpr int kTileStreamSlack = 48;                     // the 64-byte fetch of the END record stays inside the block
 
+// Slab layout as index arithmetic: the removed bits split the index into at most four fields that shift down by
+// 0..3 places; the removed bit `bit[j]` lands on physical bit top + j (unused entries: bit 63, which is never set).
+struct TileSlab {
+  u64 field[4];
+  uint8_t bit[3];
+  uint8_t top;
+  uint8_t pad[4];
+};
 struct TileArgs {
-  double2* amp;
+  double2* amp;            // the state the pass reads (and writes: amp_out == amp unless the pass re-lays the state out)
   int nrec;                // records in the stream incl. END (host bookkeeping; the device follows the stream)
   int T;                   // tile size of the pass (read by the pass-image consumers; the kernel is a template)
-  uint8_t h[11];           // ascending absolute positions of the tile's high bits
+  uint8_t h[11];           // ascending absolute positions of the tile's high bits (LOGICAL index bits)
   uint8_t order;           // bits 0-1: tile order of the launch: 0 consecutive, 1 hashed, 2 bit-reversed (see k_tile);
                            // kTileDirectIn / kTileDirectOut: the tile goes global <-> registers without LDS
   uint32_t ntiles;         // 2^(k - T)
@@ -101,12 +109,26 @@ struct TileArgs {
   //   (tid & 7) | sum_i bit(tid, 3 + i) << lay[i]  (i < 5)  |  sum_b bit(j, b) << lay[5 + b].
   // Through LDS (no direct flag) both are h[0..7] in order (element tid + 256 j of the tile).  Direct: lay_in[5..7] are
   // the bits of the FIRST register group (all above the line bits), lay_in[0..4] the other tile bits ascending --
-  // what the thread then holds IS the group's x0..x7; lay_out likewise for the LAST group.
+  // what the thread then holds IS the group's x0..x7; lay_out likewise for the LAST group.  PHYSICAL bit positions
+  // (= the logical ones unless the pass reads / writes a re-laid-out buffer, below).
   uint8_t lay_in[12];
   uint8_t lay_out[12];
-  double2* amp_out;        // probe build only: store the tiles here instead of in place (nullptr: in place)
+  double2* amp_out;        // where the tiles are stored (== amp: in place)
+  // ---- re-layout fused into the pass (round 3; all zero = none) -------------------------------------------------
+  // The buffer a pass reads (writes) may hold the state in the SLAB layout of an all-to-all re-layout (qsim_pack_all:
+  // slab d = the amplitudes whose m chosen local bits have the pattern d, sent to rank d): a bit permutation of the
+  // index -- the m bits move to the top, the others close ranks -- that keeps bits 0..2 (whole 128-B lines).  The
+  // LAST local pass before the exchange writes it and the FIRST one after it reads it, instead of two extra HBM
+  // passes of the shard (pack, unpack).
+  double2* amp_out_own;    // tiles whose logical base has (base & own_mask) == own_value are stored HERE (same layout):
+  u64 own_mask, own_value; // the slab that stays on this rank goes straight into the receive buffer
+  TileSlab slab_in, slab_out;   // where the tile with logical base b starts in amp / amp_out (kTilePermIn / kTilePermOut)
+  uint8_t nbits;           // k: index bits of the chunk
+  uint8_t perm;            // kTilePermIn | kTilePermOut | kTileOwnOut
+  uint8_t reserved[22];
   uint32_t stream[kTileStreamBytes / 4];
 };
+constexpr uint8_t kTilePermIn = 1, kTilePermOut = 2, kTileOwnOut = 4;
 constexpr uint8_t kTileDirectIn = 0x10, kTileDirectOut = 0x20, kTileOrderMask = 0x03;
 static_assert(sizeof(TileArgs) == kTileArgBytes, "kernel arguments are one 4 KiB block");
 static_assert(offsetof(TileArgs, stream) == kTileStreamOff, "record offsets are relative to the argument block");
@@ -203,8 +225,24 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
       const int p = hs[j];
       base = ((base >> p) << (p + 1)) | (base & ((1ull << p) - 1));
     }
-    return base;
+    return base;                                      // LOGICAL index of the tile's first amplitude
   };
+  // Re-laid-out buffers (TileArgs::slab_in / slab_out): the tile's position from its logical base -- wave-uniform
+  // scalar work (~25 instructions), only in the passes that carry a layout.  (The pointer is made opaque so that the
+  // loads of the masks stay where they are used: hoisted above the gate engine, which clobbers most scalar registers,
+  // they would be spilled.)
+  const unsigned perm = __builtin_amdgcn_readfirstlane((unsigned)a.perm);
+  typedef __attribute__((address_space(4))) const TileSlab cslab_t;   // read through the kernel-argument segment pointer:
+  auto slab_base = [&](u64 lbase, unsigned off) -> u64 {               // taking &a.slab_in would copy the 4 KiB block to scratch
+    cslab_t* sp = (cslab_t*)((__attribute__((address_space(4))) const char*)__builtin_amdgcn_kernarg_segment_ptr() + off);
+    asm volatile("" : "+s"(sp));
+    u64 o = (lbase & sp->field[0]) | ((lbase & sp->field[1]) >> 1) | ((lbase & sp->field[2]) >> 2) | ((lbase & sp->field[3]) >> 3);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o |= ((lbase >> sp->bit[j]) & 1ull) << (sp->top + j);
+    return o;
+  };
+  auto base_in = [&](u64 lbase) -> u64 { return (perm & kTilePermIn) ? slab_base(lbase, (unsigned)offsetof(TileArgs, slab_in)) : lbase; };
+  auto base_out = [&](u64 lbase) -> u64 { return (perm & kTilePermOut) ? slab_base(lbase, (unsigned)offsetof(TileArgs, slab_out)) : lbase; };
   typedef double amp_t __attribute__((ext_vector_type(2)));   // one amplitude as a 128-bit register operand of the engine
   typedef __attribute__((address_space(1))) amp_t gamp_t;     // ... in global memory: global_*, not flat_* (a flat access
                                                               // also counts on lgkmcnt, which the engine waits on per record)
@@ -233,18 +271,19 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
 #endif
   auto load = [&](gamp_t* p) -> amp_t { return (NT && QSIM_TILE_LOAD_NT) ? __builtin_nontemporal_load(p) : *p; };
   auto store = [&](gamp_t* p, amp_t v) { if (NT && QSIM_TILE_STORE_NT) __builtin_nontemporal_store(v, p); else *p = v; };
-#ifdef QSIM_PROBES
-  double2* const dst = a.amp_out ? a.amp_out : a.amp;
-#else
-  double2* const dst = a.amp;
-#endif
+  auto store_to = [&](u64 lbase) -> double2* {        // (uniform) which buffer this tile is stored in
+    return ((perm & kTileOwnOut) && (lbase & a.own_mask) == a.own_value) ? a.amp_out_own : a.amp_out;
+  };
   const unsigned slot0 = lds_slot(tid);               // element tid + BLOCK * j sits BLOCK * j slots further (the swizzle uses bits 4-7 only)
   static_assert(BLOCK >= 256, "lds_slot(tid + BLOCK * j) = lds_slot(tid) + BLOCK * j needs BLOCK to be a multiple of 256");
   amp_t* const tile = reinterpret_cast<amp_t*>(lds);
   u64 base = tile_base(0);
   amp_t v[PER];
+  {
+    const u64 pb = base_in(base);
 #pragma unroll
-  for (int j = 0; j < PER; ++j) v[j] = load(element(base, j, tin, rin, a.amp));
+    for (int j = 0; j < PER; ++j) v[j] = load(element(pb, j, tin, rin, a.amp));
+  }
 #pragma unroll 1
   for (int it = 0; it < TPW; ++it) {                  // (rolled: one copy of the 92 KiB engine)
     // the engine's x0..x7 (pinned to v[4:35]): the loaded tile itself when the first register group is the load
@@ -262,8 +301,9 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
     const u64 cur = base;
     if (it + 1 < TPW) {
       base = tile_base(it + 1);
+      const u64 pb = base_in(base);
 #pragma unroll
-      for (int j = 0; j < PER; ++j) v[j] = load(element(base, j, tin, rin, a.amp));
+      for (int j = 0; j < PER; ++j) v[j] = load(element(pb, j, tin, rin, a.amp));
     }
 #ifdef QSIM_PROBES
     if (it == 0) t_loaded = __builtin_readcyclecounter();
@@ -289,15 +329,17 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
 #ifdef QSIM_PROBES
     if (it == 0) t_engine = __builtin_readcyclecounter();
 #endif
+    double2* const dst = store_to(cur);
+    const u64 pcur = base_out(cur);
     if (dout) {                                       // (host: only full tiles, PER == 8)
 #pragma unroll
-      for (int j = 0; j < PER; ++j) store(element(cur, j, tout, rout, dst), x[j < 8 ? j : 0]);
+      for (int j = 0; j < PER; ++j) store(element(pcur, j, tout, rout, dst), x[j < 8 ? j : 0]);
     } else {
       amp_t w[PER];
 #pragma unroll
       for (int j = 0; j < PER; ++j) w[j] = tile[slot0 + BLOCK * j];
 #pragma unroll
-      for (int j = 0; j < PER; ++j) store(element(cur, j, tout, rout, dst), w[j]);
+      for (int j = 0; j < PER; ++j) store(element(pcur, j, tout, rout, dst), w[j]);
     }
     // the next tile's first LDS write (by the kernel or by the engine's first group change) must not overtake a
     // wave still reading this tile's last group / result

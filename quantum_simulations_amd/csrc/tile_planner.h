@@ -101,6 +101,13 @@ static int tile_order_for(const TileArgs&, int) {
   return 0;
 }
 
+// physical bit of logical index bit b under a slab layout (host mirror of k_tile's slab_base)
+static uint8_t slab_position(const TileSlab& t, int b) {
+  for (int j = 0; j < 3; ++j) if (t.bit[j] == b) return (uint8_t)(t.top + j);
+  for (int i = 0; i < 4; ++i) if ((t.field[i] >> b) & 1) return (uint8_t)(b - i);
+  return (uint8_t)b;
+}
+
 template <int T>
 static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t stream, double alg_bytes) {
   if constexpr (T > kTileBitsMax || T < kTileThreadBits) {
@@ -111,6 +118,13 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   TileArgs args = a;
   args.ntiles = (uint32_t)ntiles;
   args.order = (uint8_t)((a.order & ~kTileOrderMask) | (tile_order_for(a, T) & kTileOrderMask));
+  args.nbits = (uint8_t)c->k;
+  if (!args.amp_out) args.amp_out = args.amp;
+  // a pass that reads / writes a re-laid-out buffer: the thread layouts become physical bit positions
+  for (int i = 0; i < T - kTileLow; ++i) {
+    if (args.perm & kTilePermIn) args.lay_in[i] = slab_position(args.slab_in, args.lay_in[i]);
+    if (args.perm & kTilePermOut) args.lay_out[i] = slab_position(args.slab_out, args.lay_out[i]);
+  }
 #ifdef QSIM_PROBES
   if (getenv("QSIM_DEBUG_OUT_OF_PLACE")) {   // memory probe (WRONG results): tiles are stored into a second buffer
     static double2* other = nullptr;
@@ -134,7 +148,7 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   // thread part of an element offset: the first min(5, NH) bits of the load / store layouts: 32-bit addressing when
   // all are < 28
   bool wide = false;
-  for (int i = 0; i < kTileThreadBits - kTileLow && i < T - kTileLow; ++i) wide = wide || a.lay_in[i] >= 28 || a.lay_out[i] >= 28;
+  for (int i = 0; i < kTileThreadBits - kTileLow && i < T - kTileLow; ++i) wide = wide || args.lay_in[i] >= 28 || args.lay_out[i] >= 28;
   bool nt = c->span_bytes > tuning().mall_bytes;       // cache policy by state size (gate_plan.h)
   if (tuning().force_nt >= 0) nt = tuning().force_nt != 0;
   ProfileScope prof(6, alg_bytes, stream, nt, 32.0 * (double)amps(c));
@@ -763,8 +777,8 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
 // 0.3 ms per pass on the host, hidden behind the previous pass on the device for large states and
 // switched off for small ones; from 26 qubits on each candidate is also scored by what the pass
 // AFTER it could hold (one pass fewer on the bench circuits).  QSIM_PLAN_LOOKAHEAD = 0 / 1 / 2 forces.
-// `sink(args, T, algorithmic_bytes)` receives every planned pass: the launcher on the device path,
-// a serialiser in qsim_plan_ops (the planner itself never touches the GPU).
+// `sink(args, T, algorithmic_bytes, first, last)` receives every planned pass (first / last of the op list): the
+// launcher on the device path, a serialiser in qsim_plan_ops (the planner itself never touches the GPU).
 template <class Sink>
 static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, Sink&& sink) {
   const Tuning& tune = tuning();
@@ -974,16 +988,76 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
       for (const TileGroup& g : groups) descs += g.gates.size();
       std::fprintf(stderr, "[qsim] pass %d: %zu gates, %zu groups, %zu descriptors\n", *n_passes, n_emitted, groups.size(), descs);
     }
-    rc = sink(a, T, alg_bytes);
+    rc = sink(a, T, alg_bytes, *n_passes == 0, remaining == 0);
     if (rc) return rc;
     ++*n_passes;
   }
   return QSIM_OK;
 }
 
-static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_passes) {
-  return plan_fused(c->k, ops, n_passes, [&](TileArgs& a, int T, double alg_bytes) {
+// ---- re-layout fused into the first / last pass of an op list (qsim_apply_ops_io) -------------------------------
+// Slab layout of an all-to-all re-layout over the local bits `bits` (qsim_pack_all): amplitude i of the chunk sits at
+//   d * 2^(k - m) + (i with the m bits removed),   d = sum_j bit(i, bits[j]) << j
+// of the buffer, i.e. logical index bit bits[j] is physical bit k - m + j and the others close ranks.
+struct SlabLayout {
+  int m = 0;
+  int bits[3] = {0, 0, 0};
+};
+static void slab_descriptor(int k, const SlabLayout& L, TileSlab* t) {
+  int sorted[3] = {64, 64, 64};
+  for (int j = 0; j < L.m; ++j) sorted[j] = L.bits[j];
+  std::sort(sorted, sorted + L.m);
+  auto below = [](int b) -> u64 { return b >= 64 ? ~0ull : ((1ull << b) - 1); };
+  t->field[0] = below(sorted[0]);
+  for (int i = 1; i < 4; ++i) {
+    const int lo = sorted[i - 1], hi = i < 3 ? sorted[i] : 64;
+    t->field[i] = lo >= 64 ? 0 : (below(hi) & ~below(lo + 1));
+  }
+  for (int j = 0; j < 3; ++j) t->bit[j] = (uint8_t)(j < L.m ? L.bits[j] : 63);
+  t->top = (uint8_t)(k - L.m);
+  std::memset(t->pad, 0, sizeof t->pad);
+}
+struct FusedIo {
+  const qsim_chunk* src = nullptr;   // first pass reads this buffer (slab layout `in`) instead of the chunk
+  SlabLayout in;
+  qsim_chunk* dst = nullptr;         // last pass stores into this buffer in slab layout `out` ...
+  SlabLayout out;
+  qsim_chunk* dst_own = nullptr;     // ... except slab `own_pattern`, which goes to this one (same layout)
+  int own_pattern = -1;
+  bool fused_in = false, fused_out = false;   // results
+};
+
+static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_passes, FusedIo* io = nullptr) {
+  return plan_fused(c->k, ops, n_passes, [&](TileArgs& a, int T, double alg_bytes, bool first, bool last) {
     a.amp = c->amp;
+    a.amp_out = c->amp;
+    if (io && first && io->src) {
+      a.amp = io->src->amp;
+      a.perm |= kTilePermIn;
+      slab_descriptor(c->k, io->in, &a.slab_in);
+      io->fused_in = true;
+    }
+    if (io && last && io->dst) {
+      // the slab that stays is chosen per tile from the tile's base: its bits must lie outside the tile
+      bool clash = false;
+      for (int j = 0; j < T - kTileLow; ++j)
+        for (int i = 0; i < io->out.m; ++i) clash = clash || a.h[j] == io->out.bits[i];
+      if (!clash || io->own_pattern < 0) {
+        a.amp_out = io->dst->amp;
+        a.perm |= kTilePermOut;
+        slab_descriptor(c->k, io->out, &a.slab_out);
+        if (io->own_pattern >= 0) {
+          a.perm |= kTileOwnOut;
+          a.amp_out_own = io->dst_own->amp;
+          a.own_mask = a.own_value = 0;
+          for (int i = 0; i < io->out.m; ++i) {
+            a.own_mask |= 1ull << io->out.bits[i];
+            if ((io->own_pattern >> i) & 1) a.own_value |= 1ull << io->out.bits[i];
+          }
+        }
+        io->fused_out = true;
+      }
+    }
     if (tuning().debug_stats < 2) return launch_tile_any(a, T, c, c->stream, alg_bytes);
     // QSIM_DEBUG_STATS=2: time every pass synchronously and print its shape (profiling aid)
     hipEvent_t e0, e1;

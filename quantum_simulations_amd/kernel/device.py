@@ -146,6 +146,34 @@ class DeviceChunk:
         return lib.qsim_last_pass_count(self._h) if fused else len(ops)
 
     # ---- sync / reductions / timing -------------------------------------------------
+    def apply_ops_io(self, ops, src=None, dst=None) -> int:
+        """`apply_ops` with a re-layout fused into its ends (qsim_apply_ops_io): `src` = (chunk, bits): the state
+        is read from that chunk in the slab layout of `pack_all` over `bits`; `dst` = (chunk, bits, own_chunk,
+        own_pattern): it is left in `chunk` in slab layout, slab `own_pattern` (>= 0) in `own_chunk`.  Returns the
+        HBM passes made."""
+        nq, qs, mats = pack_ops(ops) if not (isinstance(ops, tuple) and len(ops) == 3 and isinstance(ops[0], np.ndarray)) else ops
+        io = _lib.OpsIo()
+        keep = []
+        if src is not None:
+            chunk, bits = src
+            io.src, io.src_m = chunk._h, len(bits)
+            for i, b in enumerate(bits):
+                io.src_bits[i] = int(b)
+            keep.append(chunk)
+        io.own_pattern = -1
+        if dst is not None:
+            chunk, bits, own_chunk, own_pattern = dst
+            io.dst, io.dst_m = chunk._h, len(bits)
+            for i, b in enumerate(bits):
+                io.dst_bits[i] = int(b)
+            if own_chunk is not None and own_pattern >= 0:
+                io.dst_own, io.own_pattern = own_chunk._h, int(own_pattern)
+            keep += [chunk, own_chunk]
+        passes = C.c_int()
+        _lib.check(_lib.load().qsim_apply_ops_io(self._h, len(nq), nq.ctypes.data_as(C.c_void_p), qs.ctypes.data_as(C.c_void_p),
+                                                 mats.ctypes.data_as(C.c_void_p), C.byref(io), C.byref(passes)))
+        return passes.value
+
     def sync(self) -> None:
         _lib.check(_lib.load().qsim_sync(self._h))
 
@@ -223,6 +251,20 @@ def device_count() -> int:
     return n.value
 
 
+def relayout_plan(rank: int, world: int, k: int, local_bits, global_bits, n_pieces: int = 4) -> dict:
+    """The schedule of `Comm.relayout` as a pure function of (rank, world, ...) -- qsim_comm_relayout_plan: no GPU and
+    no communicator needed.  Returns pieces, own_pattern, peers, slab_offsets (amplitudes, send = receive), piece_amps."""
+    lb, gb = np.asarray(local_bits, dtype=np.int32), np.asarray(global_bits, dtype=np.int32)
+    n_p, n_peers, own = C.c_int32(), C.c_int32(), C.c_int32()
+    peers, offs, part = np.zeros(7, dtype=np.int32), np.zeros(7, dtype=np.uint64), C.c_uint64()
+    _lib.check(_lib.load().qsim_comm_relayout_plan(int(rank), int(world), int(k), len(lb), lb.ctypes.data_as(C.c_void_p),
+                                                   gb.ctypes.data_as(C.c_void_p), int(n_pieces), C.byref(n_p), C.byref(n_peers),
+                                                   C.byref(own), peers.ctypes.data_as(C.c_void_p),
+                                                   offs.ctypes.data_as(C.c_void_p), C.byref(part)))
+    return {"pieces": n_p.value, "own_pattern": own.value, "peers": [int(x) for x in peers[:n_peers.value]],
+            "slab_offsets": [int(x) for x in offs[:n_peers.value]], "piece_amps": int(part.value)}
+
+
 class Comm:
     """RCCL communicator inside libqsim_hip.so (include/qsim_hip.h, multi-GPU reach of the C ABI): one per
     process / GPU.  `unique_id()` on rank 0, hand the 128 bytes to every rank, then `Comm(device, rank,
@@ -258,6 +300,15 @@ class Comm:
         _lib.check(_lib.load().qsim_comm_relayout(self._h, state._h, buf0._h, buf1._h, len(lb),
                                                   lb.ctypes.data_as(C.c_void_p), gb.ctypes.data_as(C.c_void_p),
                                                   int(n_pieces)))
+
+    def relayout_loopback(self, state: DeviceChunk, buf0: DeviceChunk, buf1: DeviceChunk, local_bits, global_bits,
+                          n_pieces: int, as_rank: int, as_world: int) -> None:
+        """qsim_comm_relayout's pipeline as rank `as_rank` of `as_world` would run it, every transfer looped back
+        to this rank (one GPU): the state is unchanged afterwards, buf1 holds the 'received' slabs."""
+        lb, gb = np.asarray(local_bits, dtype=np.int32), np.asarray(global_bits, dtype=np.int32)
+        _lib.check(_lib.load().qsim_comm_relayout_loopback(self._h, state._h, buf0._h, buf1._h, len(lb),
+                                                           lb.ctypes.data_as(C.c_void_p), gb.ctypes.data_as(C.c_void_p),
+                                                           int(n_pieces), int(as_rank), int(as_world)))
 
     def apply_1q_pair_remote(self, shard: DeviceChunk, buf: DeviceChunk, partner: int, my_side: int, U) -> None:
         m, p = _mat_ptr(U, 2)

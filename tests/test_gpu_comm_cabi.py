@@ -65,3 +65,37 @@ def test_world1_exchange_and_remote_pair_through_the_c_abi():
     comm.close()
     for c in (state, buf, b0, b1):
         c.close()
+
+
+def test_relayout_pipeline_loopback_runs_the_piece_loop():
+    """`qsim_comm_relayout`'s data path on ONE GPU: the schedule of rank `as_rank` in a world of
+    2 / 4 / 8 (qsim_comm_relayout_plan) with every transfer looped back to this rank -- the same packs on the chunk's
+    stream, events, transfers on the second stream in RCCL groups (piece by piece: 2^21-amplitude slabs are cut),
+    and unpacks as a real re-layout.  The slabs come back unchanged, so the state must be bit-identical afterwards
+    and the receive buffer must hold every slab but the own one at the planned offsets."""
+    from quantum_simulations_amd.kernel.device import relayout_plan
+    comm = Comm(0, 0, 1, Comm.unique_id())
+    k = 23
+    a = _rand(k, 11)
+    state, b0, b1 = DeviceChunk.from_numpy(a), DeviceChunk.zero_state(k, set_amp0=False), DeviceChunk.zero_state(k, set_amp0=False)
+    idx = np.arange(1 << k)
+    for as_world, as_rank, lb, gb, pieces in ((2, 1, [7], [0], 4), (4, 2, [0, 19], [1, 0], 2), (8, 5, [22, 3, 11], [0, 2, 1], 4),
+                                              (8, 0, [5], [1], 8)):
+        plan = relayout_plan(as_rank, as_world, k, lb, gb, pieces)
+        assert plan["pieces"] == min(pieces, 1 << (k - len(lb) - 20))          # pieces keep >= 2^20 amplitudes
+        b1.init_zero(False)
+        comm.relayout_loopback(state, b0, b1, lb, gb, pieces, as_rank, as_world)
+        state.sync()
+        np.testing.assert_array_equal(state.download(), a)
+        got = b1.download()
+        slab = 1 << (k - len(lb))
+        pat = sum(((idx >> b) & 1) << i for i, b in enumerate(lb))
+        for d in range(1 << len(lb)):
+            want = a[pat == d] if d != plan["own_pattern"] else np.zeros(slab, dtype=complex)
+            np.testing.assert_array_equal(got[d * slab:(d + 1) * slab], want, err_msg=f"world {as_world} slab {d}")
+        assert sorted(o // slab for o in plan["slab_offsets"]) == [d for d in range(1 << len(lb)) if d != plan["own_pattern"]]
+    with pytest.raises(ValueError):
+        comm.relayout_loopback(state, b0, b1, [3], [3], 1, 0, 8)      # rank bit 3 does not exist in a world of 8
+    comm.close()
+    for c in (state, b0, b1):
+        c.close()

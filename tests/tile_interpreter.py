@@ -16,7 +16,7 @@ from quantum_simulations_amd import _lib
 from quantum_simulations_amd.kernel.device import pack_ops
 
 IMAGE_BYTES = 4096
-STREAM_OFF = 64                    # byte offset of the first record (csrc/tile_kernel.h)
+STREAM_OFF = 192                   # byte offset of the first record (csrc/tile_kernel.h)
 OPC = dict(DENSE1=1, SWAP1=10, ANTI1=19, PHASE=28, DENSE2=36, REAL1=45, YLIKE1=54, PHASE_NEG=63,
            PHASE_I=71, PHASE_NI=79, DIAGR=87, PRED_OUTER=91, PRED_LANE=92, GROUP=93, GROUP_FIRST=94, END=95,
            HAD1=96, SCALE=105, ASWAP1=106, GROUP_DIRECT=115, END_DIRECT=116, PRED_OUTER_ZERO=117)
@@ -25,6 +25,9 @@ _FAMILIES = ("DENSE1", "SWAP1", "ANTI1", "PHASE", "DENSE2", "REAL1", "YLIKE1", "
              "HAD1", "SCALE", "ASWAP1")
 _IMAGE = np.dtype([("amp", "<u8"), ("nrec", "<i4"), ("T", "<i4"), ("h", "u1", (11,)), ("order", "u1"), ("ntiles", "<u4"),
                    ("lay_in", "u1", (12,)), ("lay_out", "u1", (12,)), ("amp_out", "<u8"),
+                   # re-layout fused into a pass (planned images carry none: all zero)
+                   ("amp_out_own", "<u8"), ("own_mask", "<u8"), ("own_value", "<u8"),
+                   ("slab_in", "u1", (40,)), ("slab_out", "u1", (40,)), ("nbits", "u1"), ("perm", "u1"), ("reserved", "u1", (22,)),
                    ("stream", "u1", (IMAGE_BYTES - STREAM_OFF,))])
 assert _IMAGE.itemsize == IMAGE_BYTES
 
