@@ -561,6 +561,8 @@ int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t
     if (io->own_pattern < -1 || io->own_pattern >= (1 << io->dst_m)) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: own_pattern out of range");
     if (io->own_pattern >= 0 && (rc = check_side(io->dst_own, io->dst_m, io->dst_bits, "own-slab"))) return rc;
     if (io->own_pattern >= 0 && io->dst_own->amp == io->dst->amp) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: the own-slab buffer must differ from the destination");
+    if (io->src && (io->src->amp == io->dst->amp || (io->own_pattern >= 0 && io->src->amp == io->dst_own->amp)))
+      return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: the source buffer must differ from the destination buffers (one pass may read and write them at once)");
   }
   HIP_TRY(hipSetDevice(c->device));
   std::vector<FusedOp> ops;

@@ -99,8 +99,15 @@ class HipShardBackend:
         self.torch.cuda.synchronize(self.device)
 
     # ---- arithmetic -----------------------------------------------------------------
-    def apply_ops(self, ops) -> int:
-        return self.chunk("state").apply_ops(ops)      # HBM passes (fused tile launches)
+    def apply_ops(self, ops, src=None, dst=None) -> int:
+        """HBM passes made.  src = (buffer, bits): the shard is read from that buffer in slab layout; dst = (buffer,
+        bits, own_buffer, own_pattern): it is left there in slab layout (qsim_apply_ops_io: the re-layout's pack /
+        unpack ride in the last / first fused pass)."""
+        st = self.chunk("state")
+        if src is None and dst is None:
+            return st.apply_ops(ops)
+        return st.apply_ops_io(ops, src=(self.chunk(src[0]), src[1]) if src else None,
+                               dst=(self.chunk(dst[0]), dst[1], self.chunk(dst[2]), dst[3]) if dst else None)
 
     def pack_all(self, bits, dst: str, skip_pattern: int, piece: int = 0, n_pieces: int = 1) -> None:
         self.chunk("state").pack_all(bits, self.chunk(dst), skip_pattern, piece, n_pieces)
@@ -173,7 +180,10 @@ class DryBackend:
     def sync(self) -> None:
         pass
 
-    def apply_ops(self, ops) -> int:
+    def apply_ops(self, ops, src=None, dst=None) -> int:
+        for side in (src, dst):
+            if side is not None:
+                self._check(side[1], 0, 1)
         self.local_passes += 1
         return 1
 
@@ -197,7 +207,7 @@ class DistributedEngine:
     def __init__(self, n_qubits: int, world: int, rank: int, local_rank: int = 0,
                  mode: str = "fused", backend=None, staging: bool = True,
                  staging_method: str = "belady", init_process_group: bool = True,
-                 relayout_pieces: int = 4, min_piece_qubits: int = 20):
+                 relayout_pieces: int = 4, min_piece_qubits: int = 20, fuse_relayout: bool = True):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -206,8 +216,11 @@ class DistributedEngine:
         self.n, self.world, self.rank = n_qubits, world, rank
         self.p = world.bit_length() - 1
         self.k = n_qubits - self.p
-        if self.k < 0:
-            raise ValueError("more ranks than amplitudes")
+        if self.k < 2:
+            # a dense gate on global qubits is brought local by trading places with local qubits (swap-and-stay): a
+            # 2-qubit gate needs two local places; shards of fewer than 4 amplitudes are not supported
+            raise ValueError(f"{n_qubits} qubits on {world} ranks leave {max(self.k, 0)} local qubit(s): at least 2 are needed "
+                             "(use fewer ranks)")
         self.mode, self.staging, self.staging_method = mode, staging, staging_method
         import os
         rehearsal = backend is None and os.environ.get("QSIM_DIST_BACKEND") == "gloo"
@@ -236,6 +249,12 @@ class DistributedEngine:
         self.relayout_pieces, self.min_piece_qubits = relayout_pieces, min_piece_qubits
         self._passes = self.last_passes = 0
         self._pending: list = []
+        # Re-layout fused with the neighbouring local passes (round 3): the last fused pass before an exchange stores
+        # its tiles straight into the send buffer in slab order and the first one after it loads them from the
+        # receive buffer -- no separate pack / unpack pass of the shard.  `_state_in` = (buffer, local bits) while
+        # the shard lives in a receive buffer in slab layout (None: in "state", index order).
+        self.fuse_relayout = fuse_relayout
+        self._state_in = None
 
     # ---- layout ------------------------------------------------------------------------
     @property
@@ -304,14 +323,29 @@ class DistributedEngine:
     def _queue_local(self, op) -> None:
         self._pending.append(op)
 
-    def _flush_local(self) -> None:
+    def _flush_local(self, dst=None) -> bool:
+        """Run the queued local ops (reading the shard from the receive buffer it may still live in).  With `dst`
+        = (send buffer, local bits, receive buffer, own pattern) the last pass leaves the shard in slab layout for the
+        exchange that follows; returns whether that happened (False: nothing was queued, the caller packs)."""
         if self._pending:
             ops, self._pending = self._pending, []
-            self._passes += self.backend.apply_ops(ops) or 0
+            if self._state_in is None and dst is None:
+                self._passes += self.backend.apply_ops(ops) or 0
+            else:
+                self._passes += self.backend.apply_ops(ops, src=self._state_in, dst=dst) or 0
+            self._state_in = None
+            return dst is not None
+        if self._state_in is not None:               # nothing to ride on: one unpack pass brings the shard home
+            buf, bits = self._state_in
+            self.backend.unpack_all(bits, buf, -1)
+            self._passes += 1
+            self._state_in = None
+        return False
 
     # ---- state ---------------------------------------------------------------------------
     def init_zero_state(self) -> None:
         self._pending = []
+        self._state_in = None
         self.backend.init_zero(self.rank == 0)
         self.l2p_planned = list(range(self.n))
         self._dyn = list(range(self.n))
@@ -363,8 +397,9 @@ class DistributedEngine:
         return Plan(executions, mappings, starts)
 
     def passes_per_step(self, plan: Plan) -> int:
-        """HBM passes of the last executed circuit on this rank: fused tile launches of the local
-        steps + 2 per re-layout (pack, unpack); before any execution, the op count of the plan."""
+        """HBM passes of the last executed circuit on this rank: fused tile launches of the local steps, + 1 for every
+        pack / unpack of a re-layout that could not ride in a neighbouring fused pass (2 per re-layout with
+        fuse_relayout=False); before any execution, the op count of the plan."""
         if self.last_passes:
             return self.last_passes
         return sum(len(s["local_ops"]) + len(s["nonlocal_ops"]) for s in plan.executions[0])
@@ -404,10 +439,8 @@ class DistributedEngine:
                 batch = []
                 self.apply_nonlocal(aq, U)
             self._flat_pos += 1
-        if batch:
-            ops, self._pending = self._pending + batch, []
-            self._passes += self.backend.apply_ops(ops) or 0
-        ops = step["nonlocal_ops"]
+        self._pending += batch           # runs with the next flush: before an exchange (whose pack it then absorbs),
+        ops = step["nonlocal_ops"]       # a reduction, a download, or at the end of the execution
         i = 0
         while i < len(ops):
             j = i
@@ -420,7 +453,6 @@ class DistributedEngine:
                 j += 1
             if group:
                 self.relayout(group)
-                self._passes += 2
                 self._flat_pos += j - i
                 i = j
                 continue
@@ -468,9 +500,31 @@ class DistributedEngine:
             for i, g in enumerate(glo):
                 peer = (peer & ~(1 << (g - self.k))) | (((d >> i) & 1) << (g - self.k))
             peers.append((d, peer))
-        self._flush_local()
         pieces = self._relayout_pieces(self.k - m)
         part = slab // pieces
+        if self.fuse_relayout and min(loc) >= 3 and self.k - m >= 3:
+            # fused: the queued local ops' last pass writes the slabs (own slab straight into the receive buffer), the
+            # next local pass will read them from there.  (A slab bit inside a 128-byte line would break whole-line
+            # accesses: the unfused path below handles it.)  The receive buffer must not be the one the shard
+            # currently lives in (a one-pass op list would read and write it at once): a third buffer takes turns.
+            rname = "buf2" if (self._state_in is not None and self._state_in[0] == "buf1") else "buf1"
+            recv = self.backend.tensor(rname)
+            if not self._flush_local(dst=("buf0", loc, rname, mine)):
+                self.backend.pack_all(loc, "buf0", -1)
+                self._passes += 1
+                if not self.dry:
+                    recv[mine * slab:(mine + 1) * slab].copy_(send[mine * slab:(mine + 1) * slab])
+            timer = self._comm_timer(send)
+            posted = [self._post([(peer, send[d * slab + s * part:d * slab + (s + 1) * part],
+                                   recv[d * slab + s * part:d * slab + (s + 1) * part]) for d, peer in peers])
+                      for s in range(pieces)]
+            for work in posted:
+                self._finish(work)
+            self._comm_done(timer)
+            self._state_in = (rname, list(loc))
+            return
+        self._flush_local()
+        self._passes += 2
         timer = self._comm_timer(send)
         posted = []
         self.backend.pack_all(loc, "buf0", mine, 0, pieces)        # slab d at offset d * 2^(k-m)
@@ -555,7 +609,6 @@ class DistributedEngine:
         self._trace_kind = "swap-and-stay"
         self.relayout([[v, g] for v, g in zip(victims, glob)])
         self._trace_kind = "relayout"
-        self._passes += 2
         # an UNPLANNED move: the contents of the swapped actual positions have traded places, the plans
         # do not know (a planned re-layout moves planned and actual positions alike: no update there)
         swap = {}
@@ -565,20 +618,23 @@ class DistributedEngine:
         return victims
 
     def _pick_victims(self, count: int, exclude: set) -> list[int]:
-        """Local actual bits whose next use in the running execution is farthest away (never: best)."""
+        """Local actual bits whose next use in the running execution is farthest away (never: best).  Bits inside a
+        128-byte line (0..2) come last: a slab over one of them moves 16 B per line (several times slower to pack,
+        tools/relayout_probe.py) and cannot ride in a fused pass."""
         if self.k - len(exclude) < count:
             raise ValueError("not enough local qubits to bring a global gate local")
         planned_of = {a: p for p, a in enumerate(self._dyn)}
         next_use = {}
         want = {planned_of[b] for b in range(self.k) if b not in exclude}
-        for dist, qs in enumerate(self._flat[self._flat_pos + 1:]):
-            for q in qs:
+        flat = self._flat
+        for pos in range(self._flat_pos + 1, len(flat)):
+            for q in flat[pos]:
                 if q in want and q not in next_use:
-                    next_use[q] = dist
+                    next_use[q] = pos
             if len(next_use) == len(want):
                 break
         cands = [b for b in range(self.k) if b not in exclude]
-        cands.sort(key=lambda b: (-next_use.get(planned_of[b], 1 << 60), -b))
+        cands.sort(key=lambda b: (b < 3, -next_use.get(planned_of[b], 1 << 60), -b))
         return cands[:count]
 
     def _scale(self, f) -> None:

@@ -38,8 +38,20 @@ class CpuShardBackend:
     def sync(self) -> None:
         pass
 
-    def apply_ops(self, ops) -> None:
+    def apply_ops(self, ops, src=None, dst=None) -> None:
+        """src / dst: the fused re-layout ends of qsim_apply_ops_io (runner/distributed.py), restated with the slab
+        helpers below: read the shard from a receive buffer in slab layout / leave it in slab layout for the exchange
+        (own slab in the receive buffer)."""
+        if src is not None:
+            self.unpack_all(src[1], src[0], -1)
         orc.apply_ops(self._c("state"), ops)
+        if dst is not None:
+            buf, bits, own_buf, own = dst
+            self.pack_all(bits, buf, own)
+            if own >= 0:
+                slab = 1 << (self.k - len(bits))
+                self._c(own_buf)[own * slab:(own + 1) * slab] = self._c("state")[self._slab_index(bits, own)]
+            self._c("state")[:] = np.nan          # unspecified afterwards: nobody may read it before the next src
 
     def _slab_index(self, bits, pattern: int) -> np.ndarray:
         idx = np.arange(1 << self.k, dtype=np.int64)

@@ -60,10 +60,11 @@ def _worker(rank, world, port, n, staging_modes, errors):
         from tests.cpu_shard_backend import CpuShardBackend
         p = world.bit_length() - 1
         eng = None
-        for mode_no, (staging, method) in enumerate(staging_modes):
-            # re-layouts pipelined in 4 / 2 / 1 pieces (tiny shards: lift the piece-size floor)
+        for mode_no, (staging, method, *rest) in enumerate(staging_modes):
+            # re-layouts pipelined in 4 / 2 / 1 pieces (tiny shards: lift the piece-size floor); fused with the
+            # neighbouring local passes (the default) or as separate pack / unpack passes
             eng = DistributedEngine(n, world, rank, backend=CpuShardBackend(n - p),
-                                    staging=staging, staging_method=method,
+                                    staging=staging, staging_method=method, fuse_relayout=not rest or rest[0],
                                     relayout_pieces=(4, 2, 1)[mode_no % 3], min_piece_qubits=1)
             for name, cd in _circuits(n).items():
                 want = orc.simulate(validate_circuit_dict(cd))
@@ -106,16 +107,24 @@ def _run(world, n, staging_modes):
         msgs.append(errors.get())
     for p in procs:
         if p.is_alive():
-            p.terminate()
-            msgs.append((-1, "timeout"))
+            p.kill()
+            p.join(10)
+            msgs.append((-1, "worker still running after 300 s (hung collective?): killed"))
     assert not msgs and all(p.exitcode == 0 for p in procs), "\n".join(f"[rank {r}] {m}" for r, m in msgs)
 
 
-MODES = [(True, "belady"), (True, "heuristic"), (True, "greedy"), (False, "heuristic")]
+MODES = [(True, "belady"), (True, "heuristic"), (True, "greedy"), (False, "heuristic"), (True, "belady", False),
+         (False, "heuristic", False)]
 
 
 def test_world2_gloo():
     _run(2, 6, MODES)
+
+
+def test_world2_gloo_larger_shards():
+    """7 local qubits: most re-layout bits lie above the line bits, so the fused path (slabs written by the last local
+    pass, read by the next) carries nearly every exchange."""
+    _run(2, 8, [(True, "belady"), (False, "heuristic")])
 
 
 def test_world4_gloo():
@@ -123,7 +132,16 @@ def test_world4_gloo():
 
 
 def test_world8_gloo():
-    _run(8, 7, [(True, "belady"), (True, "heuristic"), (False, "heuristic")])
+    _run(8, 7, [(True, "belady"), (True, "heuristic"), (False, "heuristic"), (False, "heuristic", False)])
+
+
+def test_two_local_qubits_is_the_minimum():
+    """k = 2 works (every dense global gate finds its victims), k < 2 is refused with a clear message."""
+    _run(4, 4, [(False, "heuristic"), (True, "belady")])
+    from quantum_simulations_amd.runner.distributed import DistributedEngine
+    from tests.cpu_shard_backend import CpuShardBackend
+    with pytest.raises(ValueError, match="at least 2"):
+        DistributedEngine(3, 4, 0, backend=CpuShardBackend(1), init_process_group=False)
 
 
 # ---- swap-and-stay: a dense gate on a global qubit moves HALF a shard, once ------------------------------
@@ -176,12 +194,11 @@ def _sas_worker(rank, world, port, errors):
         raise
 
 
-def test_swap_and_stay_bytes_and_stale_plans():
-    world = 2
+def _spawn(target, world):
     ctx = mp.get_context("spawn")
     errors = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_sas_worker, args=(r, world, port, errors)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port, errors)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -189,4 +206,60 @@ def test_swap_and_stay_bytes_and_stale_plans():
     msgs = []
     while not errors.empty():
         msgs.append(errors.get())
+    for p in procs:                       # a hung collective must not outlive the test
+        if p.is_alive():
+            p.kill()
+            p.join(10)
+            msgs.append((-1, "worker still running after 300 s (hung collective?): killed"))
     assert not msgs and all(p.exitcode == 0 for p in procs), "\n".join(f"[rank {r}] {m}" for r, m in msgs)
+
+
+def test_swap_and_stay_bytes_and_stale_plans():
+    _spawn(_sas_worker, 2)
+
+
+def _sas4_worker(rank, world, port, errors):
+    """world 4: a dense 2q gate on BOTH global qubits moves 3/4 of a shard (three peers at once); a CNOT with a global
+    control and a global, non-diagonal target moves half a shard (the target comes local on every rank)."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        sys.path.insert(0, str(ROOT))
+        from oracle import dense_oracle as orc
+        from quantum_simulations_amd.circuit.io import validate_circuit_dict
+        from quantum_simulations_amd.runner.distributed import DistributedEngine
+        from tests.cpu_shard_backend import CpuShardBackend
+        n, k = 8, 6
+        shard_bytes = 16 << k
+        u4 = np.linalg.qr(np.random.default_rng(1).standard_normal((4, 4)) + 1j * np.random.default_rng(2).standard_normal((4, 4)))[0]
+        prep = [{"qubits": [q], "gate": "RY", "params": {"theta": 0.4 + q}} for q in range(k)]    # local qubits only: nothing moves
+        cases = [([{"qubits": [n - 1, n - 2], "gate": "CU", "params": {"U": np.eye(2), "exponent": 1}}], 0, None),   # identity: nothing moves
+                 ("dense", 3, 4), ([{"qubits": [n - 1, n - 2], "gate": "CNOT"}], 1, 2), ([{"qubits": [n - 2, n - 1], "gate": "CY"}], 1, 2)]
+        for gates, exchanges, denom in cases:
+            eng = DistributedEngine(n, world, rank, backend=CpuShardBackend(k), staging=False, relayout_pieces=1,
+                                    min_piece_qubits=1)
+            eng.init_zero_state()
+            eng.execute(eng.plan({"number_of_qubits": n, "gates": prep}))
+            eng.reset_comm_stats()
+            want = orc.simulate(validate_circuit_dict({"number_of_qubits": n, "gates": prep}))
+            if gates == "dense":
+                eng.apply_nonlocal([n - 1, n - 2], u4)
+                eng._flush_local()
+                orc.apply_2q(want, n - 1, n - 2, u4)
+            else:
+                eng.execute(eng.plan({"number_of_qubits": n, "gates": gates}))
+                for g in validate_circuit_dict({"number_of_qubits": n, "gates": gates})["gates"]:
+                    orc.apply_2q(want, *g["qubits"], orc.gate_matrix(g["gate"], g["params"]))
+            stats = eng.comm_stats()
+            assert stats["exchanges"] == (1 if exchanges else 0), (gates, stats)
+            assert stats["bytes_sent_per_rank"] == (shard_bytes * exchanges // denom if exchanges else 0), (gates, stats)
+            err = float(np.max(np.abs(eng.state_vector() - want)))
+            assert err < 1e-13, (gates, err)
+            eng.backend.close()
+        eng.close()
+    except Exception:
+        errors.put((rank, traceback.format_exc()))
+        raise
+
+
+def test_two_global_qubits_move_three_quarters_of_a_shard():
+    _spawn(_sas4_worker, 4)

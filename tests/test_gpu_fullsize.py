@@ -138,8 +138,8 @@ def _worker(rank, world, port, errors, results):
         cd = _config4_circuit()
         want = _oracle_state(cd) if rank == 0 else None
         p = world.bit_length() - 1
-        for staging in (True, False):
-            eng = DistributedEngine(N4, world, rank, backend=HipShardBackend(N4 - p, 0), staging=staging)
+        for staging, fuse in ((True, True), (False, True), (True, False), (False, False)):
+            eng = DistributedEngine(N4, world, rank, backend=HipShardBackend(N4 - p, 0), staging=staging, fuse_relayout=fuse)
             assert eng.relayout_pieces == 4 and eng.min_piece_qubits == 20          # the defaults
             assert eng._relayout_pieces(N4 - p - 2) == 4                             # slabs really split
             eng.init_zero_state()
@@ -153,7 +153,7 @@ def _worker(rank, world, port, errors, results):
                     bad = np.flatnonzero(np.abs(got - want) > 1e-10)
                     print(f"[staging={staging}] {bad.size} wrong amplitudes, first {bad[:8].tolist()}, last {int(bad[-1])}, "
                           f"AND {int(np.bitwise_and.reduce(bad)):#x} OR {int(np.bitwise_or.reduce(bad)):#x}", file=sys.stderr, flush=True)
-                results.put((staging, err, norm2, stats["exchanges"], stats["bytes_sent_per_rank"]))
+                results.put((staging, fuse, err, norm2, stats["exchanges"], stats["bytes_sent_per_rank"], eng.last_passes))
             del got
             eng.backend.close()
         eng.close()
@@ -180,16 +180,26 @@ def test_config4_clifford_t_26q_four_ranks_default_pipeline():
             p.terminate()
             msgs.append((-1, "timeout"))
     assert not msgs and all(p.exitcode == 0 for p in procs), "\n".join(f"[rank {r}] {m}" for r, m in msgs)
-    seen = {}
+    seen, passes = {}, {}
     while not results.empty():
-        staging, err, norm2, exchanges, sent = results.get()
-        seen[staging] = (err, exchanges, sent)
-        assert err < 1e-10, f"staging={staging}: max |amp - C oracle| = {err}"
+        staging, fuse, err, norm2, exchanges, sent, n_passes = results.get()
+        passes[(staging, fuse)] = (n_passes, exchanges)
+        if fuse:
+            seen[staging] = (err, exchanges, sent)
+        assert err < 1e-10, f"staging={staging} fuse={fuse}: max |amp - C oracle| = {err}"
         assert abs(norm2 - 1.0) < 1e-10
-    assert set(seen) == {True, False}
+    assert set(seen) == {True, False} and len(passes) == 4
     assert 0 < seen[True][1] <= seen[False][1]                  # staging needs no more exchanges than swap-and-stay
     shard = 16 << (N4 - 2)
     assert seen[False][2] <= seen[False][1] * shard * 3 // 4    # swap-and-stay: at most 3/4 of a shard per move
+    # re-layouts fused into the neighbouring tile passes: same exchanges, same bytes, and the
+    # HBM passes of rank 0 drop by the pack + unpack of (nearly) every re-layout -- a pack / unpack survives only
+    # where no local pass is adjacent or a slab bit is a tile bit of the last pass
+    for staging in (True, False):
+        (fused, ex_f), (plain, ex_p) = passes[(staging, True)], passes[(staging, False)]
+        print(f"staging={staging}: {plain} -> {fused} HBM passes on rank 0 for {ex_p} re-layouts")
+        assert ex_f == ex_p
+        assert plain - fused >= 2 * ex_p - 3, (staging, plain, fused, ex_p)
 
 
 def test_config4_clifford_t_26q_chunked_single_gpu_runner(hip):
