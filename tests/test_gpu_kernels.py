@@ -604,3 +604,48 @@ def test_fused_phase_runs_keep_their_order(hip, n):
         dev.apply_ops(ops, fused=True)
         np.testing.assert_allclose(dev.download(), want, rtol=0, atol=1e-11, err_msg=f"n={n} seed={seed}")
         dev.close()
+
+
+def test_interleaved_fused_passes_gate_kernels_and_reductions_on_one_stream(hip):
+    """The shape of the code that exposed round 2's END_DIRECT bug: several chunks of ONE
+    allocation on ONE stream, fused passes (direct-in / direct-out ends, 2 tiles per workgroup) alternating with
+    per-gate kernels, partner-chunk butterflies and reductions, nothing synchronised in between except where a
+    result is read -- the compiler-visible registers around the engine's asm statement are reused differently by
+    every neighbour.  Every amplitude of every chunk against the oracle."""
+    k, n_chunks = 20, 4
+    parent = hip.DeviceChunk.empty(k + 2)
+    views = [parent.view(c << k, k) for c in range(n_chunks)]
+    chunks = [_rand_state(k, 1200 + c) for c in range(n_chunks)]
+    for v, c in zip(views, chunks):
+        v.upload(c)
+    rng = np.random.default_rng(77)
+    U2 = [_rand_unitary(2, 60 + i) for i in range(4)]
+    U4 = _rand_unitary(4, 70)
+    for rnd in range(3):
+        for c in range(n_chunks):
+            ops = _random_ops(k, 70, 9100 + 10 * rnd + c)
+            orc.apply_ops(chunks[c], ops)
+            assert views[c].apply_ops(ops, fused=True) >= 2
+            q = int(rng.integers(k))
+            orc.apply_1q(chunks[c], q, U2[c])
+            views[c].apply_1q(q, U2[c])                              # per-gate kernel right behind the fused passes
+            if c % 2:
+                qa, qb = (int(x) for x in rng.choice(k, size=2, replace=False))
+                orc.apply_2q(chunks[c], qa, qb, U4)
+                views[c].apply_2q(qa, qb, U4)
+            else:
+                n2 = views[c].norm2()                                # a reduction (reads the chunk, syncs)
+                assert abs(n2 - float(np.vdot(chunks[c], chunks[c]).real)) < 1e-10
+        # partner-chunk forms across the chunks, then fused passes again on their results
+        orc.apply_1q_pair(chunks[0], chunks[1], U2[rnd])
+        hip.nonlocal_.apply_1q_pair(views[0], views[1], U2[rnd])
+        orc.apply_2q_pair_qb_local(chunks[2], chunks[3], 5 + rnd, U4)
+        hip.nonlocal_.apply_2q_pair_qb_local(views[2], views[3], 5 + rnd, U4)
+        ops = _random_ops(k, 40, 9500 + rnd)
+        for c in (1, 3):
+            orc.apply_ops(chunks[c], ops)
+            views[c].apply_ops(ops, fused=True)
+    for c in range(n_chunks):
+        np.testing.assert_allclose(views[c].download(), chunks[c], rtol=0, atol=1e-10, err_msg=f"chunk {c}")
+        views[c].close()
+    parent.close()

@@ -83,7 +83,7 @@ def test_pass_counts_prove_the_fusion():
     fuse and the op list costs exactly the passes it costs in place -- two fewer than pack + passes + unpack."""
     from quantum_simulations_amd.kernel.device import DeviceChunk
     k = 20
-    state, buf0, buf1 = DeviceChunk.empty(k), DeviceChunk.empty(k), DeviceChunk.empty(k)
+    state, buf0, buf1, buf2 = DeviceChunk.empty(k), DeviceChunk.empty(k), DeviceChunk.empty(k), DeviceChunk.empty(k)
     for m, own in ((1, 0), (2, 3), (3, 5), (2, -1)):
         bits = list(range(k - m, k))[::-1]
         ops = _random_ops(k - 3, 120, 4400 + m)
@@ -93,16 +93,18 @@ def test_pass_counts_prove_the_fusion():
         state.upload(psi0)
         plain_passes = state.apply_ops(ops)
         assert plain_passes >= 2
-        buf1.upload(np.concatenate(_slabs(psi0, bits)))
-        buf0.init_zero(False)
+        buf2.upload(np.concatenate(_slabs(psi0, bits)))       # (the source must be a third buffer: one pass may read
+        buf0.init_zero(False)                                 # it while it writes the destinations)
         state.init_zero(False)
-        passes = state.apply_ops_io(ops, src=(buf1, bits), dst=(buf0, bits, buf1 if own >= 0 else None, own))
+        passes = state.apply_ops_io(ops, src=(buf2, bits), dst=(buf0, bits, buf1 if own >= 0 else None, own))
         assert passes == plain_passes, (m, own, passes, plain_passes)
+        with pytest.raises(ValueError, match="source buffer must differ"):
+            state.apply_ops_io(ops, src=(buf1, bits), dst=(buf0, bits, buf1, max(own, 0)))
         slab = 1 << (k - m)
         g0, g1 = buf0.download(), buf1.download()
         for d, w in enumerate(_slabs(want, bits)):
             np.testing.assert_allclose((g1 if d == own else g0)[d * slab:(d + 1) * slab], w, rtol=0, atol=1e-11, err_msg=f"m={m} slab {d}")
-    for c in (state, buf0, buf1):
+    for c in (state, buf0, buf1, buf2):
         c.close()
 
 
@@ -114,10 +116,11 @@ def test_single_pass_both_ends_and_argument_checks():
     ops = [([5], orc.gate_matrix("H")), ([5, 9], orc.gate_matrix("CNOT")), ([2], orc.gate_matrix("T"))]
     want = psi0.copy()
     orc.apply_ops(want, ops)
-    buf1.upload(np.concatenate(_slabs(psi0, [12, 4])))
-    assert state.apply_ops_io(ops, src=(buf1, [12, 4]), dst=(buf0, [13], buf1, 1)) == 1      # ONE pass does it all
+    buf2 = DeviceChunk.from_numpy(np.concatenate(_slabs(psi0, [12, 4])))
+    assert state.apply_ops_io(ops, src=(buf2, [12, 4]), dst=(buf0, [13], buf1, 1)) == 1      # ONE pass does it all
     np.testing.assert_allclose(buf0.download()[:1 << (k - 1)], _slabs(want, [13])[0], rtol=0, atol=1e-12)
     np.testing.assert_allclose(buf1.download()[1 << (k - 1):], _slabs(want, [13])[1], rtol=0, atol=1e-12)
+    buf2.close()
     with pytest.raises(ValueError):
         state.apply_ops_io(ops, dst=(state, [5], None, -1))          # destination must be another buffer
     with pytest.raises(ValueError):

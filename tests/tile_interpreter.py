@@ -92,6 +92,10 @@ def records(img):
             assert seen_group, "gate before the first group"
             blk, case = int(d[3]) & 0xFFFF, (int(d[3]) >> 16) // 4
             outer = int(d[2]) << 3
+            # the second dispatch of a predicated gate may only reach a gate case (the engine's control-flow checks,
+            # tests/test_engine_asm_static.py, rely on it)
+            assert any(OPC[f] <= case < OPC[f] + (9 if f in ("DENSE1", "SWAP1", "ANTI1", "DENSE2", "REAL1", "YLIKE1", "HAD1", "ASWAP1")
+                                                   else 8 if f.startswith("PHASE") else 4 if f == "DIAGR" else 1) for f in _FAMILIES), case
             if entry == OPC["PRED_LANE"]:
                 assert blk
             elif entry == OPC["PRED_OUTER_ZERO"]:      # the listed outer bits must all be 0: reported as a NEGATIVE mask
