@@ -76,6 +76,38 @@ def _plan_fingerprint(steps, k: int, use_fusion: bool, use_staging: bool, stagin
             "steps_sha256": h.hexdigest()}
 
 
+def _check_plan_sidecar(work: Path, first_step: int, fingerprint: dict) -> None:
+    """`done_steps` of a checkpoint indexes the step list of the run that wrote it.  This build records the planner
+    flags next to `wal.json` (`plan.json`) and refuses to resume under a different plan.  A checkpoint WITHOUT the
+    sidecar was written by the reference (wenbo_engine/runner/single_node.py:78-138 knows no sidecar) or by a round-1
+    build: it is accepted only for an unstaged plan -- there both implementations produce the same step list for the
+    same `chunk_size` / `use_fusion` (pinned bit-exactly by tests/golden/planner.json), which the caller vouches for by
+    passing the flags of the original run -- and the sidecar is written then.  Staged plans differ between the two
+    (`strict_order`, wal.py), so a staged resume needs the sidecar."""
+    plan_path = work / "plan.json"
+    if first_step == 0:
+        work.mkdir(parents=True, exist_ok=True)
+        plan_path.write_text(json.dumps(fingerprint))
+        return
+    try:
+        saved = json.loads(plan_path.read_text())
+    except OSError:
+        saved = None
+    except ValueError:
+        raise ValueError(f"{plan_path} is not valid JSON; refusing to resume")
+    if saved is None:
+        if fingerprint["use_staging"]:
+            raise ValueError(f"checkpoint in {work} has no plan.json (written by the reference or an older build) and this "
+                             "run is staged: staged step lists differ between the implementations; refusing to resume")
+        if first_step > fingerprint["n_steps"]:
+            raise ValueError(f"checkpoint in {work} has {first_step} steps done, this plan has only {fingerprint['n_steps']}")
+        plan_path.write_text(json.dumps(fingerprint))
+        return
+    if saved != fingerprint:
+        raise ValueError(f"checkpoint in {work} was written under a different plan (chunk_size / use_fusion / "
+                         f"use_staging / staging_method): saved {saved}, now {fingerprint}; refusing to resume")
+
+
 def run(circuit_dict: dict, work_dir: str | Path | None = None, chunk_size: int = 1 << 20,
         kernel: str = "hip", use_wal: bool = True, use_fencing: bool = False,
         use_fusion: bool = False, use_staging: bool = False,
@@ -105,21 +137,10 @@ def run(circuit_dict: dict, work_dir: str | Path | None = None, chunk_size: int 
         from quantum_simulations_amd.storage.block_store import load_to_device, write_state
         from quantum_simulations_amd.wal import WAL
         log = WAL(work / "wal.json", circuit_dict=cd)   # raises on a different circuit
-        first_step = min(log.done_steps, len(steps))
+        first_step = log.done_steps
         fingerprint = _plan_fingerprint(steps, k, use_fusion, use_staging, staging_method)
-        plan_path = work / "plan.json"
-        if first_step > 0:
-            # done_steps indexes THIS step list only if the checkpoint was planned with the same flags
-            try:
-                saved = json.loads(plan_path.read_text())
-            except (OSError, ValueError):
-                saved = None
-            if saved != fingerprint:
-                raise ValueError(f"checkpoint in {work} was written under a different plan (chunk_size / use_fusion / "
-                                 f"use_staging / staging_method): saved {saved}, now {fingerprint}; refusing to resume")
-        else:
-            work.mkdir(parents=True, exist_ok=True)
-            plan_path.write_text(json.dumps(fingerprint))
+        _check_plan_sidecar(work, first_step, fingerprint)
+        first_step = min(first_step, len(steps))
     if first_step > 0:
         state = load_to_device(work / f"state_{log.committed_buf}", device)
         if state.k != n:

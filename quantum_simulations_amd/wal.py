@@ -8,7 +8,9 @@ hex digits).  Resuming ACROSS the two implementations is limited to what both ag
 reference does not -- w_qft(6) at k = 3 is 9 steps here, 7 there -- so `done_steps` would point at
 different gates) checkpointed as complex64 (`checkpoint_dtype="complex64"`: the reference's
 `Manifest.validate` rejects any other dtype).  This build's own resume additionally checks the planner
-flags through the `plan.json` sidecar (runner/single_node.py).  The GPU runner commits every
+flags through the `plan.json` sidecar (runner/single_node.py); a directory WITHOUT the sidecar -- what the reference
+writes -- resumes for unstaged plans (the caller passes the original run's chunk_size / use_fusion) and is refused for
+staged ones.  The GPU runner commits every
 `checkpoint_every` steps instead of every step: the state lives in HBM and a checkpoint is a full
 download.
 """

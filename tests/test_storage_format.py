@@ -104,3 +104,31 @@ def test_complex128_buffer_directory_round_trip(tmp_path):
     np.testing.assert_array_equal(block_store.read_state(d), psi)     # lossless
     with pytest.raises(ValueError, match="unsupported dtype"):
         block_store.write_state(tmp_path / "x", psi, chunk_size=16, dtype="float32")
+
+
+def test_plan_sidecar_rules(tmp_path):
+    """runner/single_node._check_plan_sidecar (no GPU): fresh run writes plan.json; a resume needs the same plan; a
+    directory without the sidecar (reference-written) resumes only unstaged plans and gets its sidecar then."""
+    import json
+    from quantum_simulations_amd.runner.single_node import _check_plan_sidecar, _plan_fingerprint
+    import numpy as np
+    steps = [{"local_ops": [([0], np.eye(2))], "nonlocal_ops": []}, {"local_ops": [], "nonlocal_ops": [([3, 1], np.eye(4))]}]
+    plain = _plan_fingerprint(steps, 3, False, False, "heuristic")
+    staged = _plan_fingerprint(steps, 3, False, True, "heuristic")
+    w = tmp_path / "a"
+    _check_plan_sidecar(w, 0, plain)
+    assert json.loads((w / "plan.json").read_text()) == plain
+    _check_plan_sidecar(w, 1, plain)                                   # same plan: fine
+    with pytest.raises(ValueError, match="different plan"):
+        _check_plan_sidecar(w, 1, _plan_fingerprint(steps, 4, False, False, "heuristic"))
+    (w / "plan.json").unlink()
+    with pytest.raises(ValueError, match="no plan.json"):
+        _check_plan_sidecar(w, 1, staged)
+    with pytest.raises(ValueError, match="only 2"):
+        _check_plan_sidecar(w, 5, plain)
+    assert not (w / "plan.json").exists()
+    _check_plan_sidecar(w, 2, plain)                                   # unstaged: accepted, sidecar written
+    assert json.loads((w / "plan.json").read_text()) == plain
+    (w / "plan.json").write_text("{not json")
+    with pytest.raises(ValueError, match="not valid JSON"):
+        _check_plan_sidecar(w, 1, plain)
