@@ -842,16 +842,19 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
   auto mask_of = [](const std::vector<int>& bits, size_t n) { u64 m = 0; for (size_t i = 0; i < n && i < bits.size(); ++i) m |= 1ull << bits[i]; return m; };
   // candidate tiles for the next pass from the current `done` / `first`: [0] = first come, then the
   // look-ahead ones grown from the first `seed` claimed bits
+  u64 forced = 0;                               // (probe) bits that every tile holds
+  for (int b = low; b < low + tune.plan_force_low && b < k && __builtin_popcountll(forced) < cap; ++b) forced |= 1ull << b;
+  const int n_forced = __builtin_popcountll(forced);
   auto candidates = [&](std::vector<u64>* out, size_t max_seed, size_t seed_step) {
     std::vector<int> claimed;                   // high bits in the order they were claimed
     {
-      u64 blocked = 0, mask = 0;
+      u64 blocked = 0, mask = forced;
       int count = 0;
       for (size_t i = first; i < n_ops && count < tune.max_gates_per_pass; ++i) {
         if (done[i]) continue;
         bool ok = !(blocked & qm[i]);
         const u64 extra = need[i] & ~mask;
-        if (ok && (int)claimed.size() + __builtin_popcountll(extra) > cap) ok = false;
+        if (ok && n_forced + (int)claimed.size() + __builtin_popcountll(extra) > cap) ok = false;
         if (!ok) { blocked |= qm[i]; if (blocked == all_qubits) break; continue; }
         for (u64 e = extra; e; e &= e - 1) claimed.push_back(__builtin_ctzll(e));
         mask |= extra;
@@ -859,10 +862,10 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
       }
     }
     out->clear();
-    out->push_back(mask_of(claimed, claimed.size()));
+    out->push_back(forced | mask_of(claimed, claimed.size()));
     if (!(lookahead && k - low > cap) || holds(out->front(), nullptr) >= kSaturated) return;
     for (size_t seed = 0; seed <= max_seed && seed <= claimed.size(); seed += seed_step) {
-      u64 mask = mask_of(claimed, seed);
+      u64 mask = forced | mask_of(claimed, seed);
       while (__builtin_popcountll(mask) < cap) {
         int pick = -1, pick_count = -(1 << 20);
         for (int b = low; b < k; ++b) {

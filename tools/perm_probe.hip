@@ -14,6 +14,8 @@
 //          2: the same in two halves (real, imaginary) through 16 KiB; 0: no LDS.  occ=4|5|8: waves per SIMD (lds 0 / 2);
 //   pad    bytes of unused dynamic LDS per workgroup (caps the workgroups per CU: 160 KiB in 1280-byte granules)
 //   plain  1: plain loads, 2: plain stores, 3: both (default: non-temporal)
+//   lay    which tile bit (index into the sorted R) each in-tile position takes: 5 thread bits (3 lane, 2 wave), then the 3 bits of
+//          a thread's 8 accesses; default 0,1,...,7
 //   ro / wo  reads only / writes only (16 B per amplitude)
 //   order  0 consecutive tiles in flight, 1 XCD-contiguous (each XCD walks one eighth), 2 bit-reversed
 // Prints milliseconds per pass (median of 7) and TB/s moved (32 B per amplitude), and checks the result
@@ -163,6 +165,7 @@ int main(int argc, char** argv) {
     for (int b = 0; b < 40; ++b) a.pi[b] = (unsigned char)b;
     bool inplace = false;
     int tpw = 2, lds = 1, occ = 4, pad = 0;
+    for (int i = 0; i < 8; ++i) a.lay[i] = (unsigned char)i;
     std::string name = argv[s];
     bool ok = true;
     for (const std::string& part : split(argv[s], ';')) {
@@ -180,6 +183,11 @@ int main(int argc, char** argv) {
       } else if (part == "inplace") inplace = true;
       else if (part.rfind("tpw=", 0) == 0) tpw = atoi(part.c_str() + 4);
       else if (part.rfind("lds=", 0) == 0) lds = atoi(part.c_str() + 4);
+      else if (part.rfind("lay=", 0) == 0) {
+        auto v = split(part.substr(4), ',');
+        if (v.size() != 8) { ok = false; break; }
+        for (int i = 0; i < 8; ++i) a.lay[i] = (unsigned char)atoi(v[i].c_str());
+      }
       else if (part.rfind("pad=", 0) == 0) pad = atoi(part.c_str() + 4);
       else if (part.rfind("occ=", 0) == 0) occ = atoi(part.c_str() + 4);
       else if (part.rfind("order=", 0) == 0) a.order = atoi(part.c_str() + 6);
@@ -194,7 +202,6 @@ int main(int argc, char** argv) {
     for (int b = 0; b < 3; ++b) if (a.pi[b] != b) ok = false;
     for (int i = 0; i < 8; ++i) if (a.R[i] < 3 || a.R[i] >= n || (i && a.R[i] == a.R[i - 1])) ok = false;
     if (!ok) { printf("bad spec: %s\n", argv[s]); continue; }
-    for (int i = 0; i < 8; ++i) a.lay[i] = (unsigned char)i;
     a.src = A;
     a.dst = inplace ? A : B;
     a.ntiles = (unsigned)(N >> 11);
