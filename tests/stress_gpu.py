@@ -34,6 +34,29 @@ while time.time() - t0 < budget:
         err = float(np.max(np.abs(dev.download() - want)))
         worst = max(worst, err)
         assert err < 1e-10, (n, seed, fused, err)
+    if n >= 4:               # the same op list with a re-layout fused into its ends (qsim_apply_ops_io), random slab bits
+        m = int(rng.integers(1, min(3, n - 1) + 1))
+        bits_in = [int(b) for b in rng.choice(n, size=m, replace=False)]
+        bits_out = [int(b) for b in rng.choice(n, size=m, replace=False)]
+        own = int(rng.integers(-1, 1 << m))
+        idx = np.arange(1 << n)
+
+        def slabs(vec, bits):
+            pat = sum(((idx >> b) & 1) << i for i, b in enumerate(bits))
+            return [vec[pat == d] for d in range(1 << len(bits))]
+        src, dst, keep = DeviceChunk.from_numpy(np.concatenate(slabs(psi0, bits_in))), DeviceChunk.empty(n), DeviceChunk.empty(n)
+        dst.init_zero(False)
+        keep.init_zero(False)
+        dev.init_zero(False)
+        dev.apply_ops_io(ops, src=(src, bits_in), dst=(dst, bits_out, keep if own >= 0 else None, own))
+        g0, g1 = dst.download(), keep.download()
+        slab = (1 << n) >> m
+        for d, w in enumerate(slabs(want, bits_out)):
+            err = float(np.max(np.abs((g1 if d == own else g0)[d * slab:(d + 1) * slab] - w)))
+            worst = max(worst, err)
+            assert err < 1e-10, ("io", n, seed, bits_in, bits_out, own, d, err)
+        for c in (src, dst, keep):
+            c.close()
     dev.close()
     if n >= 2 and n <= 12:   # chunked runner with a random chunk size, from |0..0>
         names = ["H", "X", "T", "CNOT", "CZ", "SWAP", "CY"]

@@ -112,6 +112,50 @@ def test_config3_every_target_amplitudes_30q(hip):
     dev.close()
 
 
+def test_slab_layouts_at_30_qubits_64_bit_offsets(hip):
+    """qsim_apply_ops_io at full shard size (30 local qubits, the multi-GPU configuration): slab bits at the top of the
+    index push tile bits to physical positions >= 28 (the 64-bit-offset instantiations of k_tile) on both sides.
+    A circuit goes out through the slab layout of one bit set and its inverse comes back in through it: sampled
+    amplitudes of the result must equal the initial state (a wrong tile position anywhere breaks the identity)."""
+    from quantum_simulations_amd.circuits import random_1q_cx_circuit
+    from quantum_simulations_amd.kernel import gates as gt
+    n = 30
+    state, send, recv = hip.DeviceChunk.empty(n), hip.DeviceChunk.empty(n), hip.DeviceChunk.empty(n)
+    plain, packed = hip.DeviceChunk.empty(n), hip.DeviceChunk.empty(n)
+    state.init_random(77)
+    rng = np.random.default_rng(5)
+    windows = [int(o) for o in rng.integers(0, (1 << n) - (1 << 12), size=24)] + [0, (1 << n) - (1 << 12)]
+    before = {o: state.download(o, 1 << 12) for o in windows}
+    cd = random_1q_cx_circuit(n, depth=6, seed=30)
+    ops = [(g["qubits"], gt.gate_matrix(g["gate"], g.get("params", {}))) for g in cd["gates"]]
+    inv = [(qs, U.conj().T) for qs, U in reversed(ops)]
+    for bits, own in (([29, 28], 2), ([28, 12, 29], 5), ([5], -1)):
+        m = len(bits)
+        slab = (1 << n) >> m
+        windows = [o for o in windows if o // slab == (o + (1 << 12) - 1) // slab]      # (windows inside one slab)
+        plain.copy_from(state)
+        plain.apply_ops(ops)
+        plain.pack_all(bits, packed, -1)                      # the independent slab kernel: what the fused store must equal
+        recv.init_zero(False)
+        p1 = state.apply_ops_io(ops, dst=(send, bits, recv if own >= 0 else None, own))
+        for o in windows:
+            d = o // slab
+            got = (recv if d == own else send).download(o, 1 << 12)
+            np.testing.assert_allclose(got, packed.download(o, 1 << 12), rtol=0, atol=1e-13, err_msg=f"{bits} slab {d} at {o}")
+        # "exchange" with itself: every slab but the own one moves from the send to the receive buffer
+        for d in range(1 << m):
+            if d != own:
+                recv.view(d * slab, n - m).copy_from(send.view(d * slab, n - m))
+        p2 = state.apply_ops_io(inv, src=(recv, bits))
+        assert p1 >= 1 and p2 >= 1
+        for o in windows:
+            err = float(np.max(np.abs(state.download(o, 1 << 12) - before[o])))
+            assert err < 1e-11, (bits, own, o, err)
+    assert abs(state.norm2() - 1.0) < 1e-10
+    for c in (state, send, recv, plain, packed):
+        c.close()
+
+
 N4 = 26
 
 
