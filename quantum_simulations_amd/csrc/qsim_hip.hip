@@ -27,6 +27,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <list>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -280,7 +281,7 @@ int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* q
     if (classify_op(nq[i], qubits + 2 * i, mats + 32 * (size_t)i, &o)) ops.push_back(o);
   }
   int passes = 0;
-  rc = run_fused(c, ops, &passes);
+  rc = run_fused(c, ops, &passes, nullptr, n_ops, nq, qubits, mats);
   c->last_passes = passes;
   return rc;
 }
@@ -593,7 +594,7 @@ int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t
   }
   if (tiles) {
     int p = 0;
-    if ((rc = run_fused(c, ops, &p, &fio))) return rc;
+    if ((rc = run_fused(c, ops, &p, &fio, n_ops, nq, qubits, mats))) return rc;
     passes += p;
     if (fio.src && !fio.fused_in) return fail(QSIM_ERR_INVALID, "internal: the first pass did not take the source buffer");
   } else {

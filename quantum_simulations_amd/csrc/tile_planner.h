@@ -1030,51 +1030,124 @@ struct FusedIo {
   bool fused_in = false, fused_out = false;   // results
 };
 
-static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_passes, FusedIo* io = nullptr) {
-  return plan_fused(c->k, ops, n_passes, [&](TileArgs& a, int T, double alg_bytes, bool first, bool last) {
-    a.amp = c->amp;
-    a.amp_out = c->amp;
-    if (io && first && io->src) {
-      a.amp = io->src->amp;
-      a.perm |= kTilePermIn;
-      slab_descriptor(c->k, io->in, &a.slab_in);
-      io->fused_in = true;
-    }
-    if (io && last && io->dst) {
-      // the slab that stays is chosen per tile from the tile's base: its bits must lie outside the tile
-      bool clash = false;
-      for (int j = 0; j < T - kTileLow; ++j)
-        for (int i = 0; i < io->out.m; ++i) clash = clash || a.h[j] == io->out.bits[i];
-      if (!clash || io->own_pattern < 0) {
-        a.amp_out = io->dst->amp;
-        a.perm |= kTilePermOut;
-        slab_descriptor(c->k, io->out, &a.slab_out);
-        if (io->own_pattern >= 0) {
-          a.perm |= kTileOwnOut;
-          a.amp_out_own = io->dst_own->amp;
-          a.own_mask = a.own_value = 0;
-          for (int i = 0; i < io->out.m; ++i) {
-            a.own_mask |= 1ull << io->out.bits[i];
-            if ((io->own_pattern >> i) & 1) a.own_value |= 1ull << io->out.bits[i];
-          }
+// One planned pass on its way to the device: buffers, the re-layout of the op list's ends, launch.
+static int launch_planned(qsim_chunk* c, TileArgs& a, int T, double alg_bytes, bool first, bool last, FusedIo* io) {
+  a.amp = c->amp;
+  a.amp_out = c->amp;
+  a.amp_out_own = nullptr;
+  a.perm = 0;
+  if (io && first && io->src) {
+    a.amp = io->src->amp;
+    a.perm |= kTilePermIn;
+    slab_descriptor(c->k, io->in, &a.slab_in);
+    io->fused_in = true;
+  }
+  if (io && last && io->dst) {
+    // the slab that stays is chosen per tile from the tile's base: its bits must lie outside the tile
+    bool clash = false;
+    for (int j = 0; j < T - kTileLow; ++j)
+      for (int i = 0; i < io->out.m; ++i) clash = clash || a.h[j] == io->out.bits[i];
+    if (!clash || io->own_pattern < 0) {
+      a.amp_out = io->dst->amp;
+      a.perm |= kTilePermOut;
+      slab_descriptor(c->k, io->out, &a.slab_out);
+      if (io->own_pattern >= 0) {
+        a.perm |= kTileOwnOut;
+        a.amp_out_own = io->dst_own->amp;
+        a.own_mask = a.own_value = 0;
+        for (int i = 0; i < io->out.m; ++i) {
+          a.own_mask |= 1ull << io->out.bits[i];
+          if ((io->own_pattern >> i) & 1) a.own_value |= 1ull << io->out.bits[i];
         }
-        io->fused_out = true;
       }
+      io->fused_out = true;
     }
-    if (tuning().debug_stats < 2) return launch_tile_any(a, T, c, c->stream, alg_bytes);
-    // QSIM_DEBUG_STATS=2: time every pass synchronously and print its shape (profiling aid)
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, c->stream);
-    const int rc = launch_tile_any(a, T, c, c->stream, alg_bytes);
-    (void)hipEventRecord(e1, c->stream);
-    (void)hipEventSynchronize(e1);
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    std::fprintf(stderr, "[qsim] timed pass: %.3f ms, %d records, high bits", ms, a.nrec);
-    for (int j = 0; j < T - kTileLow; ++j) std::fprintf(stderr, " %d", a.h[j]);
-    std::fprintf(stderr, "\n");
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    return rc;
+  }
+  if (tuning().debug_stats < 2) return launch_tile_any(a, T, c, c->stream, alg_bytes);
+  // QSIM_DEBUG_STATS=2: time every pass synchronously and print its shape (profiling aid)
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, c->stream);
+  const int rc = launch_tile_any(a, T, c, c->stream, alg_bytes);
+  (void)hipEventRecord(e1, c->stream);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  std::fprintf(stderr, "[qsim] timed pass: %.3f ms, %d records, high bits", ms, a.nrec);
+  for (int j = 0; j < T - kTileLow; ++j) std::fprintf(stderr, " %d", a.h[j]);
+  std::fprintf(stderr, "\n");
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return rc;
+}
+
+// ---- plan cache ---------------------------------------------------------------------------------------------------
+// Runners execute the same op list again and again (a planned circuit repeated, one plan per chunk of a chunked run):
+// the pass images of the last few op lists are kept, keyed by the exact bytes of the call (local qubits, arities,
+// qubits, matrices), and launched again without planning.  Planning overlaps with the device for large states (the
+// images of pass p + 1 are made while pass p runs), so this matters where passes are short: 13 % of a step at 22
+// qubits, nothing at 28.  Images are stored without buffers or layouts: those are put in at
+// launch time (launch_planned), so one entry serves every chunk of its size and every re-layout.
+struct CachedPass { TileArgs a; int T; double alg_bytes; };
+struct CachedPlan {
+  int k = 0;
+  u64 hash = 0;
+  std::vector<unsigned char> key;        // nq | qubits | mats of the call
+  std::vector<CachedPass> passes;
+};
+constexpr size_t kPlanCacheEntries = 8;
+constexpr size_t kPlanCacheMaxKeyBytes = 4u << 20;      // longer op lists are planned every time
+static std::list<CachedPlan> g_plan_cache;             // most recently used first
+static std::mutex g_plan_cache_mu;
+
+static u64 fnv1a(const unsigned char* p, size_t n, u64 h = 1469598103934665603ull) {
+  for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_passes, FusedIo* io = nullptr,
+                     int n_ops = 0, const int32_t* nq = nullptr, const int32_t* qubits = nullptr, const double* mats = nullptr) {
+  // key of the call (only when the caller handed the raw op list over)
+  std::vector<unsigned char> key;
+  u64 hash = 0;
+  const size_t key_bytes = (size_t)n_ops * (sizeof(int32_t) * 3 + sizeof(double) * 32);
+  const bool cacheable = nq && qubits && mats && n_ops > 0 && key_bytes <= kPlanCacheMaxKeyBytes && tuning().debug_stats == 0;
+  if (cacheable) {
+    key.resize(key_bytes);
+    unsigned char* w = key.data();
+    std::memcpy(w, nq, sizeof(int32_t) * (size_t)n_ops); w += sizeof(int32_t) * (size_t)n_ops;
+    std::memcpy(w, qubits, sizeof(int32_t) * 2 * (size_t)n_ops); w += sizeof(int32_t) * 2 * (size_t)n_ops;
+    std::memcpy(w, mats, sizeof(double) * 32 * (size_t)n_ops);
+    hash = fnv1a(key.data(), key.size(), 1469598103934665603ull ^ (u64)c->k);
+    std::vector<CachedPass> hit;
+    {
+      std::lock_guard<std::mutex> lock(g_plan_cache_mu);
+      for (auto it = g_plan_cache.begin(); it != g_plan_cache.end(); ++it)
+        if (it->hash == hash && it->k == c->k && it->key == key) {
+          g_plan_cache.splice(g_plan_cache.begin(), g_plan_cache, it);
+          hit = g_plan_cache.front().passes;
+          break;
+        }
+    }
+    if (!hit.empty()) {
+      for (size_t p = 0; p < hit.size(); ++p) {
+        const int rc = launch_planned(c, hit[p].a, hit[p].T, hit[p].alg_bytes, p == 0, p + 1 == hit.size(), io);
+        if (rc) return rc;
+      }
+      *n_passes = (int)hit.size();
+      return QSIM_OK;
+    }
+  }
+  std::vector<CachedPass> made;
+  const int rc = plan_fused(c->k, ops, n_passes, [&](TileArgs& a, int T, double alg_bytes, bool first, bool last) {
+    if (cacheable) made.push_back(CachedPass{a, T, alg_bytes});      // (before buffers and layouts go in)
+    return launch_planned(c, a, T, alg_bytes, first, last, io);
   });
+  if (rc == QSIM_OK && cacheable && !made.empty()) {
+    std::lock_guard<std::mutex> lock(g_plan_cache_mu);
+    g_plan_cache.emplace_front();
+    CachedPlan& e = g_plan_cache.front();
+    e.k = c->k; e.hash = hash; e.key.swap(key); e.passes.swap(made);
+    while (g_plan_cache.size() > kPlanCacheEntries) g_plan_cache.pop_back();
+  }
+  return rc;
 }

@@ -649,3 +649,58 @@ def test_interleaved_fused_passes_gate_kernels_and_reductions_on_one_stream(hip)
         np.testing.assert_allclose(views[c].download(), chunks[c], rtol=0, atol=1e-10, err_msg=f"chunk {c}")
         views[c].close()
     parent.close()
+
+
+def test_plan_cache_reuses_plans_and_tells_op_lists_apart(hip):
+    """qsim_apply_ops keeps the pass images of the last op lists (csrc/tile_planner.h, plan cache): an identical call
+    launches them again without planning -- on another chunk, inside a re-layout -- and anything that differs in a
+    single matrix entry, qubit or size is planned afresh.  Every result against the oracle."""
+    n = 14
+    base = _random_ops(n, 80, 4242)
+    variants = []
+    for i in range(11):                                        # more op lists than the cache holds (8): evictions
+        ops = list(base)
+        ops[7 * i % len(ops)] = ([i % n], orc.gate_matrix("RY", {"theta": 0.1 + 0.01 * i}))
+        variants.append(ops)
+    tweaked = list(base)
+    qs, U = tweaked[40]
+    tweaked[40] = (qs, U * np.exp(1e-9j))                      # the same list but for one matrix, by 1e-9
+    moved = [([(q + 1) % n for q in qs], U) for qs, U in base]  # the same matrices on other qubits
+    a, b = hip.DeviceChunk.empty(n), hip.DeviceChunk.empty(n)
+    for rnd in range(2):
+        for idx, ops in enumerate([base] + variants + [base, tweaked, moved, base]):
+            psi = _rand_state(n, 1000 * rnd + idx)
+            want = psi.copy()
+            orc.apply_ops(want, ops)
+            dev = a if (rnd + idx) % 2 else b
+            dev.upload(psi)
+            dev.apply_ops(ops)
+            np.testing.assert_allclose(dev.download(), want, rtol=0, atol=1e-11, err_msg=f"round {rnd} list {idx}")
+    # a global phase of 1e-9 on one matrix must show (a stale plan would not carry it)
+    psi = _rand_state(n, 5)
+    a.upload(psi)
+    a.apply_ops(base)
+    r0 = a.download()
+    a.upload(psi)
+    a.apply_ops(tweaked)
+    assert 1e-13 < float(np.max(np.abs(a.download() - r0))) < 1e-9          # (amplitudes ~ 2^-7, phase 1e-9)
+    # the cached plan of `base` inside a fused re-layout, and on a chunk of another size (no hit: planned for 15 qubits)
+    send, recv = hip.DeviceChunk.empty(n), hip.DeviceChunk.empty(n)
+    idx = np.arange(1 << n)
+    pat = ((idx >> 9) & 1) | (((idx >> 12) & 1) << 1)
+    want = psi.copy()
+    orc.apply_ops(want, base)
+    recv.init_zero(False)
+    a.upload(psi)
+    a.apply_ops_io(base, dst=(send, [9, 12], recv, 1))
+    slab = (1 << n) >> 2
+    for d in range(4):
+        got = (recv if d == 1 else send).download(d * slab, slab)
+        np.testing.assert_allclose(got, want[pat == d], rtol=0, atol=1e-11)
+    big = hip.DeviceChunk.from_numpy(_rand_state(n + 1, 6))
+    want = big.download()
+    orc.apply_ops(want, base)
+    big.apply_ops(base)
+    np.testing.assert_allclose(big.download(), want, rtol=0, atol=1e-11)
+    for c in (a, b, send, recv, big):
+        c.close()
