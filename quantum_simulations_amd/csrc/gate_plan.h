@@ -45,7 +45,7 @@ struct Tuning {
                              // a 1q gate moves past ops it commutes with and merges with its neighbour 1q gate on the qubit: 0 off, 1 forward (the earlier gate moves), 2 backward (the later one moves: fewer passes)
   int tile_mux = 1;          // a controlled gate with its control outside the tile + the 1q gate next to it on its target -> two predicated 2x2 records
   int plan_conflict_cost = -1; // pass builder, bank / row conflict pairs of tile bits: > 0 = ops a pass must hold more to be worth one (costs passes), -1 = break ties only (-1.9 % over 8 circuits), 0 = ignore
-  int plan_commute = 1;      // pass builder: an op that has to wait blocks a qubit it acts on DIAGONALLY (control, phase bit) only for ops that
+  int plan_commute = 2;      // (1: diagonal qubits only, 2: also X-type targets) pass builder: an op that has to wait blocks a qubit it acts on DIAGONALLY (control, phase bit) only for ops that
                              // act on it non-diagonally -- ops that are diagonal on every shared qubit commute, so later ones may pass it
   int plan_force_low = 0;    // probe: the lowest N index bits above the line bits (3 .. 3 + N - 1) are tile bits of EVERY pass (2^(N+7)-byte
                              // contiguous pieces per tile: full DRAM rows on the write side, profiles/r03e_perm_windows_28q.txt)

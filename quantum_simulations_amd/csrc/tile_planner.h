@@ -769,7 +769,8 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
 // bits has to wait and blocks its qubits: its TARGET qubits for every later op, its diagonal qubits (controls,
 // phase bits) only for later ops that target them -- two ops that act diagonally on every qubit they share commute
 // (CNOTs with a common control, a phase gate on a control, CZ / CR among themselves), so the later one may run a
-// pass earlier than the one that waits (round 3: 155 -> 150 passes over 8 random circuits at 28 qubits, 93 -> 84
+// pass earlier than the one that waits; likewise ops that act as 1 or X on a shared qubit (CNOTs with a common
+// target, X on a CNOT target) (round 3: 155 -> 148 passes over 8 random circuits at 28 qubits, 93 -> 84
 // over 6 Clifford+T circuits, 21 -> 20 on the 30-qubit bench circuit; tuning().plan_commute).  Ops on disjoint
 // qubits commute anyway; everything else keeps its list order.  WHICH qubits become the tile's
 // high bits decides how many ops a pass holds:
@@ -797,20 +798,26 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
   std::vector<char> done(n_ops, 0);
   std::vector<u64> qm(n_ops), need(n_ops);     // all qubits of an op; its target bits above the low bits
   std::vector<u64> tm(n_ops);                  // the qubits an op acts on NON-diagonally (its targets); qm & ~tm: controls, phase bits
+  std::vector<u64> xm(n_ops);                  // ... of those, the ones it acts on as 1 or X only (X, CNOT targets): X-diagonal
   for (size_t i = 0; i < n_ops; ++i) {
     qm[i] = op_qmask(ops[i]);
     need[i] = 0;
-    tm[i] = 0;
+    tm[i] = xm[i] = 0;
     for (int t = 0; t < ops[i].ntargets; ++t) {
       tm[i] |= 1ull << ops[i].target[t];
       if (ops[i].target[t] >= low) need[i] |= 1ull << ops[i].target[t];
     }
+    if (ops[i].kind == TG_SWAP1 && tune.plan_commute >= 2) xm[i] = tm[i];
     if (!tune.plan_commute) tm[i] = qm[i];     // (off: every qubit of a waiting op blocks everything on it)
   }
   // Two ops commute when each acts diagonally on every qubit they share (CNOTs with a common control, a phase gate on
-  // a control, CZ / CR among themselves ...).  An op that has to wait therefore blocks its TARGET qubits for everything
-  // and its diagonal qubits only for ops that target them: `bt` = qubits blocked for all, `bd` = blocked for targets.
-  auto admissible = [&](size_t i, u64 bt, u64 bd) { return !(qm[i] & bt) && !(tm[i] & bd); };
+  // a control, CZ / CR among themselves ...) -- or, plan_commute >= 2, both as 1 / X (CNOTs with a common target, X on a
+  // CNOT target).  An op that has to wait therefore blocks its general TARGET qubits for everything, its diagonal
+  // qubits for ops that target them and its X-type targets for everything but X-type targets:
+  // `bt` = qubits blocked for all, `bd` = blocked for targets, `bx` = blocked for all but X-type targets.
+  auto admissible3 = [&](size_t i, u64 bt, u64 bd, u64 bx) {
+    return !(qm[i] & bt) && !(tm[i] & bd) && !((qm[i] & ~xm[i]) & bx);
+  };
   const u64 all_qubits = k >= 64 ? ~0ull : ((1ull << k) - 1);
   const bool lookahead = tune.plan_lookahead >= 0 ? tune.plan_lookahead != 0 : k >= 24;
   size_t remaining = n_ops;
@@ -818,12 +825,13 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
   *n_passes = 0;
   // ops a pass with the given high bits would hold (optionally listed)
   auto holds = [&](u64 tile_mask, std::vector<size_t>* out) -> int {
-    u64 bt = 0, bd = 0;
+    u64 bt = 0, bd = 0, bx = 0;
     int count = 0;
     for (size_t i = first; i < n_ops && count < tune.max_gates_per_pass; ++i) {
       if (done[i]) continue;
-      if (!admissible(i, bt, bd) || (need[i] & ~tile_mask)) {
-        bt |= tm[i];
+      if (!admissible3(i, bt, bd, bx) || (need[i] & ~tile_mask)) {
+        bt |= tm[i] & ~xm[i];
+        bx |= xm[i];
         bd |= qm[i] & ~tm[i];
         if (bt == all_qubits) break;
         continue;
@@ -862,14 +870,14 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
   auto candidates = [&](std::vector<u64>* out, size_t max_seed, size_t seed_step) {
     std::vector<int> claimed;                   // high bits in the order they were claimed
     {
-      u64 bt = 0, bd = 0, mask = forced;
+      u64 bt = 0, bd = 0, bx = 0, mask = forced;
       int count = 0;
       for (size_t i = first; i < n_ops && count < tune.max_gates_per_pass; ++i) {
         if (done[i]) continue;
-        bool ok = admissible(i, bt, bd);
+        bool ok = admissible3(i, bt, bd, bx);
         const u64 extra = need[i] & ~mask;
         if (ok && n_forced + (int)claimed.size() + __builtin_popcountll(extra) > cap) ok = false;
-        if (!ok) { bt |= tm[i]; bd |= qm[i] & ~tm[i]; if (bt == all_qubits) break; continue; }
+        if (!ok) { bt |= tm[i] & ~xm[i]; bx |= xm[i]; bd |= qm[i] & ~tm[i]; if (bt == all_qubits) break; continue; }
         for (u64 e = extra; e; e &= e - 1) claimed.push_back(__builtin_ctzll(e));
         mask |= extra;
         ++count;
