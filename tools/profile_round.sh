@@ -12,11 +12,11 @@ mkdir -p $R/gpurun_out
 cd $R && python3 bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 tail -c 600 gpurun_out/${tag}_bench.json; echo
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep --sustain-seconds 0 > $R/gpurun_out/${tag}_bench_under_rocprof.json 2> $R/gpurun_out/prof_trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep --fused-qubits 0 --sustain-seconds 0 > $R/gpurun_out/${tag}_bench_under_rocprof.json 2> $R/gpurun_out/prof_trace.err
 echo trace rc=$?
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-sweep --sustain-seconds 0 > /dev/null 2> $R/gpurun_out/prof_pmc_fetch.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-sweep --fused-qubits 0 --sustain-seconds 0 > /dev/null 2> $R/gpurun_out/prof_pmc_fetch.err
 echo fetch rc=$?
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-sweep --sustain-seconds 0 > /dev/null 2> $R/gpurun_out/prof_pmc_write.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-sweep --fused-qubits 0 --sustain-seconds 0 > /dev/null 2> $R/gpurun_out/prof_pmc_write.err
 echo write rc=$?
 cd $R
 python3 tools/pmc_summary.py $tag gpurun_out/prof_trace gpurun_out/prof_pmc_fetch gpurun_out/prof_pmc_write

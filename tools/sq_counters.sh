@@ -10,7 +10,7 @@ cd /tmp
 i=0
 for set in "SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_SMEM SQ_INSTS_LDS" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU" "SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM" "SQ_INSTS_VMEM SQ_INSTS_BRANCH" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/sq_$i -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-sweep --sustain-seconds 0 > /dev/null 2> $R/gpurun_out/sq_$i.err || echo "set '$set' failed"
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/sq_$i -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-sweep --fused-qubits 0 --sustain-seconds 0 > /dev/null 2> $R/gpurun_out/sq_$i.err || echo "set '$set' failed"
 done
 cd $R
 python3 - "$tag" <<'PY'
