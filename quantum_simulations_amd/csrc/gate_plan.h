@@ -47,6 +47,7 @@ struct Tuning {
   int plan_conflict_cost = -1; // pass builder, bank / row conflict pairs of tile bits: > 0 = ops a pass must hold more to be worth one (costs passes), -1 = break ties only (-1.9 % over 8 circuits), 0 = ignore
   int plan_commute = 2;      // (1: diagonal qubits only, 2: also X-type targets) pass builder: an op that has to wait blocks a qubit it acts on DIAGONALLY (control, phase bit) only for ops that
                              // act on it non-diagonally -- ops that are diagonal on every shared qubit commute, so later ones may pass it
+  int plan_jitter = 0;       // probe: > 0 seeds pseudo-random tie-breaks (and losses of up to two ops) in the pass builder's growth choices
   int plan_force_low = 0;    // probe: the lowest N index bits above the line bits (3 .. 3 + N - 1) are tile bits of EVERY pass (2^(N+7)-byte
                              // contiguous pieces per tile: full DRAM rows on the write side, profiles/r03e_perm_windows_28q.txt)
   int tile_sink_swaps = 1;   // X / CNOT that nothing later in their group touches: swap LDS addresses at write-back (OPC_ASWAP1)
@@ -76,6 +77,7 @@ struct Tuning {
     if (const char* e = getenv("QSIM_TILE_DIRECT")) tile_direct = atoi(e);
     if (const char* e = getenv("QSIM_PLAN_CONFLICT_COST")) plan_conflict_cost = atoi(e);
     if (const char* e = getenv("QSIM_PLAN_COMMUTE")) plan_commute = atoi(e);
+    if (const char* e = getenv("QSIM_PLAN_JITTER")) plan_jitter = atoi(e);
     if (const char* e = getenv("QSIM_PLAN_FORCE_LOW")) plan_force_low = std::max(0, std::min(6, atoi(e)));
     if (const char* e = getenv("QSIM_TILE_MUX")) tile_mux = atoi(e);
     if (const char* e = getenv("QSIM_TILE_COMMUTE_FUSE")) tile_commute_fuse = atoi(e);

@@ -860,7 +860,12 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
   const bool tie_break = tune.plan_conflict_cost < 0;
   // (the fitted per-bit + pair model of the same samples as the tie-break instead of the conflict count: 159 instead of
   // 155 passes over 8 circuits, +2.3 % time -- breaking every tie perturbs the greedy growth more than it saves)
-  auto keyed = [&](int count, u64 mask) -> int { return tie_break ? count * 64 - conflicts(mask) : count; };
+  u64 jit_state = 0x9E3779B97F4A7C15ull * (u64)(tune.plan_jitter + 1);
+  auto jitter = [&]() -> unsigned { jit_state ^= jit_state << 13; jit_state ^= jit_state >> 7; jit_state ^= jit_state << 17; return (unsigned)(jit_state >> 33); };
+  auto keyed = [&](int count, u64 mask) -> int {
+    if (tune.plan_jitter > 0) return (count - (int)(jitter() % 8 == 0) - (int)(jitter() % 16 == 0)) * 64 + (int)(jitter() % 64);
+    return tie_break ? count * 64 - conflicts(mask) : count;
+  };
   auto mask_of = [](const std::vector<int>& bits, size_t n) { u64 m = 0; for (size_t i = 0; i < n && i < bits.size(); ++i) m |= 1ull << bits[i]; return m; };
   // candidate tiles for the next pass from the current `done` / `first`: [0] = first come, then the
   // look-ahead ones grown from the first `seed` claimed bits
