@@ -204,6 +204,14 @@ int qsim_apply_2q_pair_qb_local_remote(qsim_comm* comm, qsim_chunk* shard, qsim_
                                        int my_side, int qb, const double U[32]);
 
 /* ---- synchronisation, reductions, timing ------------------------------------------- */
+/* ---- sparse view (the v3 worker's rows; v3_hisvsim_spark parallel_gate_applicator.py:372-374, state_manager.py:95-106) ---
+ * The amplitudes with |re| > eps or |im| > eps as rows (index, re, im), ascending by index, selected ON THE DEVICE:
+ * qsim_count_nonzero counts them; qsim_export_nonzero writes up to `capacity` rows into host arrays and returns the
+ * total in *n_rows (when it exceeds the capacity nothing is written: come back with room, or download the dense
+ * state). */
+int qsim_count_nonzero(qsim_chunk* c, double eps, uint64_t* count);
+int qsim_export_nonzero(qsim_chunk* c, double eps, uint64_t capacity, uint64_t* out_idx, double* out_re_im,
+                        uint64_t* n_rows);
 int qsim_sync(qsim_chunk* c);
 int qsim_norm2(qsim_chunk* c, double* out);               /* sum |amp|^2               */
 /* max_i |amp_i - expected_i| for closed-form states, evaluated on the device:

@@ -80,6 +80,8 @@ SIGNATURES = {
     "qsim_apply_1q_pair_remote": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "qsim_apply_2q_pair_qa_local_remote": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "qsim_apply_2q_pair_qb_local_remote": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "qsim_count_nonzero": (C.c_int, [_P, C.c_double, C.POINTER(C.c_uint64)]),
+    "qsim_export_nonzero": (C.c_int, [_P, C.c_double, C.c_uint64, _P, _P, C.POINTER(C.c_uint64)]),
     "qsim_sync": (C.c_int, [_P]),
     "qsim_norm2": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "qsim_max_abs_err_closed_form": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64,

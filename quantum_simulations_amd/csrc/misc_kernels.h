@@ -188,6 +188,42 @@ __global__ __launch_bounds__(kBlock) void k_norm2_partial(const double2* p, u64 
   block_reduce_store<false>(acc, partial);
 }
 
+// ---- sparse view of the state: the v3 worker's rows (idx, re, im) with its pruning rule |re| > eps or |im| > eps
+// (parallel_gate_applicator.py:372-374, state_manager.py:95-106), made on the device: a GHZ state of 30 qubits has two
+// rows, not 16 GiB.  One pass counts, a second one appends the kept amplitudes (one atomic per wave reserves the slots;
+// the rows arrive unordered and are sorted by index on the host).
+__device__ __forceinline__ bool kept_amp(double2 v, double eps) { return fabs(v.x) > eps || fabs(v.y) > eps; }
+
+__global__ __launch_bounds__(kBlock) void k_count_kept(const double2* p, u64 n, double eps, unsigned long long* count) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  unsigned long long mine = 0;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) mine += kept_amp(p[i], eps) ? 1u : 0u;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, mine);
+}
+
+__global__ __launch_bounds__(kBlock) void k_append_kept(const double2* p, u64 n, double eps, unsigned long long* cursor,
+                                                        u64 capacity, u64* out_idx, double2* out_amp) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  const u64 rounds = (n + stride - 1) / stride;        // every lane runs every round (the ballot needs whole waves)
+  for (u64 r = 0; r < rounds; ++r) {
+    const u64 i = r * stride + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const double2 v = i < n ? p[i] : make_double2(0.0, 0.0);
+    const bool keep = i < n && kept_amp(v, eps);
+    const unsigned long long mask = __ballot(keep);
+    if (!mask) continue;
+    const int lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(cursor, (unsigned long long)__popcll(mask));
+    base = __shfl(base, 0, 64);
+    if (keep) {
+      const u64 at = base + (u64)__popcll(mask & ((1ull << lane) - 1));
+      if (at < capacity) { out_idx[at] = i; out_amp[at] = v; }
+    }
+  }
+}
+
 // kind 0: GHZ, kind 1: GHZ+QFT closed form.  `base` = global index of amp 0.
 struct BitPerm { unsigned char to_logical[64]; int active; };   // physical index bit -> logical qubit
 

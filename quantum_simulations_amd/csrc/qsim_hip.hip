@@ -823,6 +823,66 @@ int qsim_apply_2q_pair_qb_local_remote(qsim_comm* cm, qsim_chunk* shard, qsim_ch
   return my_side == 0 ? qsim_apply_2q_pair_qb_local(shard, buf, qb, U) : qsim_apply_2q_pair_qb_local(buf, shard, qb, U);
 }
 
+// Sparse export: the amplitudes with |re| > eps or |im| > eps as rows (index, re, im), ascending by index.
+int qsim_count_nonzero(qsim_chunk* c, double eps, uint64_t* count) {
+  int rc = check_chunk(c, "qsim_count_nonzero");
+  if (rc) return rc;
+  if (!count || !(eps >= 0)) return fail(QSIM_ERR_INVALID, "qsim_count_nonzero: bad arguments");
+  if ((rc = ensure_scratch(c))) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  unsigned long long* dcount = reinterpret_cast<unsigned long long*>(c->scratch);
+  HIP_TRY(hipMemsetAsync(dcount, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_count_kept, dim3(stream_grid(amps(c))), dim3(kBlock), 0, c->stream, c->amp, amps(c), eps, dcount);
+  HIP_TRY(hipGetLastError());
+  unsigned long long host = 0;
+  HIP_TRY(hipMemcpyAsync(&host, dcount, sizeof host, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *count = host;
+  return QSIM_OK;
+}
+
+int qsim_export_nonzero(qsim_chunk* c, double eps, uint64_t capacity, uint64_t* out_idx, double* out_re_im, uint64_t* n_rows) {
+  int rc = check_chunk(c, "qsim_export_nonzero");
+  if (rc) return rc;
+  if (!n_rows || !(eps >= 0) || (capacity && (!out_idx || !out_re_im))) return fail(QSIM_ERR_INVALID, "qsim_export_nonzero: bad arguments");
+  if ((rc = ensure_scratch(c))) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  u64* didx = nullptr;
+  double2* damp = nullptr;
+  if (capacity) {
+    if (hipMalloc((void**)&didx, sizeof(u64) * capacity) != hipSuccess) return fail(QSIM_ERR_NOMEM, "qsim_export_nonzero: no device memory for %llu rows", (u64)capacity);
+    if (hipMalloc((void**)&damp, sizeof(double2) * capacity) != hipSuccess) { (void)hipFree(didx); return fail(QSIM_ERR_NOMEM, "qsim_export_nonzero: no device memory for %llu rows", (u64)capacity); }
+  }
+  unsigned long long* cursor = reinterpret_cast<unsigned long long*>(c->scratch);
+  auto cleanup = [&]() { if (didx) (void)hipFree(didx); if (damp) (void)hipFree(damp); };
+  hipError_t e = hipMemsetAsync(cursor, 0, sizeof(unsigned long long), c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_append_kept, dim3(stream_grid(amps(c))), dim3(kBlock), 0, c->stream, c->amp, amps(c), eps, cursor, (u64)capacity, didx, damp);
+    e = hipGetLastError();
+  }
+  unsigned long long total = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&total, cursor, sizeof total, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  const u64 got = std::min<u64>(total, capacity);
+  std::vector<u64> idx(got);
+  std::vector<double2> amp(got);
+  if (e == hipSuccess && got) e = hipMemcpy(idx.data(), didx, sizeof(u64) * got, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && got) e = hipMemcpy(amp.data(), damp, sizeof(double2) * got, hipMemcpyDeviceToHost);
+  cleanup();
+  if (e != hipSuccess) return fail(QSIM_ERR_HIP, "qsim_export_nonzero: %s", hipGetErrorString(e));
+  *n_rows = total;
+  if (total > capacity) return QSIM_OK;             // the caller sees n_rows > capacity and comes back with room (nothing written)
+  std::vector<u64> order(got);
+  for (u64 i = 0; i < got; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](u64 a, u64 b) { return idx[a] < idx[b]; });
+  for (u64 i = 0; i < got; ++i) {
+    out_idx[i] = idx[order[i]];
+    out_re_im[2 * i] = amp[order[i]].x;
+    out_re_im[2 * i + 1] = amp[order[i]].y;
+  }
+  return QSIM_OK;
+}
+
 int qsim_sync(qsim_chunk* c) {
   int rc = check_chunk(c, "qsim_sync");
   if (rc) return rc;

@@ -177,6 +177,26 @@ class DeviceChunk:
     def sync(self) -> None:
         _lib.check(_lib.load().qsim_sync(self._h))
 
+    def count_nonzero(self, eps: float = 1e-15) -> int:
+        """Amplitudes with |re| > eps or |im| > eps (v3's pruning rule), counted on the device."""
+        n = C.c_uint64()
+        _lib.check(_lib.load().qsim_count_nonzero(self._h, float(eps), C.byref(n)))
+        return int(n.value)
+
+    def export_nonzero(self, eps: float = 1e-15, capacity: int | None = None):
+        """(indices uint64[m], amplitudes complex128[m]) of the kept amplitudes, ascending by index, selected on the
+        device (no dense download); None when there are more than `capacity` of them."""
+        if capacity is None:
+            capacity = self.count_nonzero(eps)
+        idx = np.empty(capacity, dtype=np.uint64)
+        amp = np.empty(capacity, dtype=np.complex128)
+        n = C.c_uint64()
+        _lib.check(_lib.load().qsim_export_nonzero(self._h, float(eps), int(capacity), idx.ctypes.data_as(C.c_void_p),
+                                                   amp.ctypes.data_as(C.c_void_p), C.byref(n)))
+        if n.value > capacity:
+            return None
+        return idx[:n.value], amp[:n.value]
+
     def norm2(self) -> float:
         out = C.c_double()
         _lib.check(_lib.load().qsim_norm2(self._h, C.byref(out)))

@@ -63,3 +63,34 @@ def test_gpu_driver_matches_v3_worker_rows():
     with pytest.raises(ValueError, match="different qubits"):
         ParallelGateApplicator().apply_gates_parallel(state, [{"qubits": [0], "gate": "H"}, {"qubits": [0], "gate": "X"}])
     state.close()
+
+
+@pytest.mark.gpu
+def test_sparse_rows_are_selected_on_the_device():
+    """qsim_count_nonzero / qsim_export_nonzero: v3's surviving rows (|re| > 1e-15 or |im| > 1e-15, ascending index)
+    without a dense download -- against numpy on the downloaded state for sparse, half-empty and dense states, and a
+    30-qubit GHZ through the Driver (2 rows of 2^30: a dense download would move 16 GiB)."""
+    from quantum_simulations_amd import circuits as gen
+    from quantum_simulations_amd.driver import Driver
+    from quantum_simulations_amd.kernel.device import DeviceChunk
+    rng = np.random.default_rng(12)
+    for k, density in ((5, 1.0), (13, 0.01), (16, 0.5), (20, 0.0005), (21, 1.0)):
+        psi = (rng.standard_normal(1 << k) + 1j * rng.standard_normal(1 << k)) * (rng.random(1 << k) < density)
+        psi[rng.integers(0, 1 << k, 4)] = 3e-16 + 0j               # below the threshold: pruned
+        psi[rng.integers(0, 1 << k, 4)] = 4e-16j + 2e-15            # real part above it: kept
+        dev = DeviceChunk.from_numpy(psi.astype(np.complex128))
+        keep = np.nonzero((np.abs(psi.real) > 1e-15) | (np.abs(psi.imag) > 1e-15))[0]
+        assert dev.count_nonzero() == len(keep)
+        idx, amp = dev.export_nonzero()
+        np.testing.assert_array_equal(idx, keep.astype(np.uint64))
+        np.testing.assert_array_equal(amp, psi[keep])
+        if len(keep) > 1:
+            assert dev.export_nonzero(capacity=len(keep) - 1) is None      # no room: nothing written, the count says so
+        assert dev.count_nonzero(eps=10.0) == 0 and len(dev.export_nonzero(eps=10.0)[0]) == 0
+        dev.close()
+    with Driver() as drv:
+        res = drv.run_circuit(gen.generate_ghz_circuit(30))
+        rows = drv.get_state_dict(res)
+        assert sorted(rows) == [0, (1 << 30) - 1]
+        assert all(abs(v - 2 ** -0.5) < 1e-12 for v in rows.values())
+        res.final_state.close()
