@@ -66,6 +66,10 @@ int qsim_init_zero(qsim_chunk* c, int set_amp0);          /* |0..0> when set_amp
 int qsim_init_random(qsim_chunk* c, uint64_t seed);       /* normalised, counter-based  */
 int qsim_upload(qsim_chunk* c, const double* re_im, uint64_t offset_amps, uint64_t count);
 int qsim_download(qsim_chunk* c, double* re_im, uint64_t offset_amps, uint64_t count);
+/* complex64 (re, im as floats) transfers: the reference's chunk files are complex64 (wenbo_engine/storage/
+ * block_store.py:11); the conversion (round to nearest even) runs on the device, 8 bytes per amplitude cross PCIe. */
+int qsim_download_c64(qsim_chunk* c, float* re_im, uint64_t offset_amps, uint64_t count);
+int qsim_upload_c64(qsim_chunk* c, const float* re_im, uint64_t offset_amps, uint64_t count);
 int qsim_copy(qsim_chunk* dst, const qsim_chunk* src);    /* device-to-device, same k  */
 
 /* ---- local butterflies (cpu_scalar.apply_1q / apply_2q) --------------------------- */

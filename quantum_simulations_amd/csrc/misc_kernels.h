@@ -188,6 +188,24 @@ __global__ __launch_bounds__(kBlock) void k_norm2_partial(const double2* p, u64 
   block_reduce_store<false>(acc, partial);
 }
 
+// ---- complex64 <-> complex128 on the device: the reference's chunk files are complex64 (storage/block_store.py:11),
+// so an export rounds on the GPU and moves 8 B per amplitude over PCIe instead of 16 (round to nearest even, what
+// numpy's astype(complex64) does)
+__global__ __launch_bounds__(kBlock) void k_to_c64(float2* __restrict__ dst, const double2* __restrict__ src, u64 n) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double2 v = src[i];
+    dst[i] = make_float2(__double2float_rn(v.x), __double2float_rn(v.y));
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_from_c64(double2* __restrict__ dst, const float2* __restrict__ src, u64 n) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float2 v = src[i];
+    dst[i] = make_double2((double)v.x, (double)v.y);
+  }
+}
+
 // ---- sparse view of the state: the v3 worker's rows (idx, re, im) with its pruning rule |re| > eps or |im| > eps
 // (parallel_gate_applicator.py:372-374, state_manager.py:95-106), made on the device: a GHZ state of 30 qubits has two
 // rows, not 16 GiB.  One pass counts, a second one appends the kept amplitudes (one atomic per wave reserves the slots;

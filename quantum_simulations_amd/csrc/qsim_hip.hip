@@ -205,6 +205,45 @@ int qsim_download(qsim_chunk* c, double* re_im, uint64_t offset_amps, uint64_t c
   return QSIM_OK;
 }
 
+// complex64 transfers (the reference's chunk-file dtype): converted on the device through a staging buffer
+static int c64_transfer(qsim_chunk* c, float* host, uint64_t offset_amps, uint64_t count, bool download, const char* what) {
+  int rc = check_chunk(c, what);
+  if (rc) return rc;
+  if (!host && count) return fail(QSIM_ERR_INVALID, "%s: host buffer is null", what);
+  if (offset_amps > amps(c) || count > amps(c) - offset_amps)
+    return fail(QSIM_ERR_INVALID, "%s: range [%llu, +%llu) outside chunk of %llu", what, (u64)offset_amps, (u64)count, amps(c));
+  if (!count) return QSIM_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const u64 piece = std::min<u64>(count, 1ull << 24);
+  float2* stage = nullptr;
+  if (hipMalloc((void**)&stage, sizeof(float2) * piece) != hipSuccess) return fail(QSIM_ERR_NOMEM, "%s: no device memory for the staging buffer", what);
+  hipError_t e = hipSuccess;
+  for (u64 done = 0; done < count && e == hipSuccess; done += piece) {
+    const u64 n = std::min<u64>(piece, count - done);
+    if (download) {
+      hipLaunchKernelGGL(k_to_c64, dim3(stream_grid(n)), dim3(kBlock), 0, c->stream, stage, (const double2*)(c->amp + offset_amps + done), n);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipMemcpyAsync(host + 2 * done, stage, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream);
+    } else {
+      e = hipMemcpyAsync(stage, host + 2 * done, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_from_c64, dim3(stream_grid(n)), dim3(kBlock), 0, c->stream, c->amp + offset_amps + done, (const float2*)stage, n);
+        e = hipGetLastError();
+      }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // (the staging buffer is reused)
+  }
+  (void)hipFree(stage);
+  if (e != hipSuccess) return fail(QSIM_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  return QSIM_OK;
+}
+int qsim_download_c64(qsim_chunk* c, float* re_im, uint64_t offset_amps, uint64_t count) {
+  return c64_transfer(c, re_im, offset_amps, count, true, "qsim_download_c64");
+}
+int qsim_upload_c64(qsim_chunk* c, const float* re_im, uint64_t offset_amps, uint64_t count) {
+  return c64_transfer(c, const_cast<float*>(re_im), offset_amps, count, false, "qsim_upload_c64");
+}
+
 int qsim_copy(qsim_chunk* dst, const qsim_chunk* src) {
   int rc = check_chunk(dst, "qsim_copy");
   if (rc || (rc = check_chunk(src, "qsim_copy"))) return rc;

@@ -116,6 +116,17 @@ class DeviceChunk:
         _lib.check(_lib.load().qsim_download(self._h, out.ctypes.data_as(C.c_void_p), offset, count))
         return out
 
+    def download_c64(self, offset: int = 0, count: int | None = None) -> np.ndarray:
+        """Amplitudes as complex64, rounded on the device (the reference's chunk-file dtype)."""
+        count = len(self) - offset if count is None else count
+        out = np.empty(count, dtype=np.complex64)
+        _lib.check(_lib.load().qsim_download_c64(self._h, out.ctypes.data_as(C.c_void_p), int(offset), int(count)))
+        return out
+
+    def upload_c64(self, arr: np.ndarray, offset: int = 0) -> None:
+        a = np.ascontiguousarray(arr, dtype=np.complex64)
+        _lib.check(_lib.load().qsim_upload_c64(self._h, a.ctypes.data_as(C.c_void_p), int(offset), int(a.size)))
+
     def copy_from(self, other: "DeviceChunk") -> None:
         _lib.check(_lib.load().qsim_copy(self._h, other._h))
 

@@ -60,7 +60,9 @@ def write_state(directory: str | Path, state, chunk_size: int = 1 << 20,
     (d / "chunks").mkdir(parents=True, exist_ok=True)
     names = []
     for c in range(total // chunk_size):
-        if hasattr(state, "download"):
+        if dtype == "complex64" and hasattr(state, "download_c64"):
+            part = state.download_c64(c * chunk_size, chunk_size)     # rounded on the device: half the PCIe bytes
+        elif hasattr(state, "download"):
             part = state.download(c * chunk_size, chunk_size)
         else:
             part = np.asarray(state[c * chunk_size:(c + 1) * chunk_size])
@@ -105,5 +107,8 @@ def load_to_device(directory: str | Path, device: int = 0):
     dt = DTYPES[m.get("dtype", "complex64")]
     for c, name in enumerate(m["chunks"]):
         part = np.fromfile(str(Path(directory) / "chunks" / name), dtype=dt)
-        dev.upload(part.astype(np.complex128), offset=c * m["chunk_size"])
+        if dt is np.complex64:
+            dev.upload_c64(part, offset=c * m["chunk_size"])            # widened on the device
+        else:
+            dev.upload(part, offset=c * m["chunk_size"])
     return dev

@@ -132,3 +132,32 @@ def test_plan_sidecar_rules(tmp_path):
     (w / "plan.json").write_text("{not json")
     with pytest.raises(ValueError, match="not valid JSON"):
         _check_plan_sidecar(w, 1, plain)
+
+
+@pytest.mark.gpu
+def test_complex64_transfers_round_on_the_device_like_numpy():
+    """qsim_download_c64 / qsim_upload_c64 (chunk-file export / import): bit-identical to numpy's astype(complex64) of
+    the downloaded complex128 state -- ties, values that round up to the next binade, float-denormal results, signed
+    zeros -- and the widening upload is exact."""
+    from quantum_simulations_amd.kernel.device import DeviceChunk
+    rng = np.random.default_rng(64)
+    k = 18
+    psi = (rng.standard_normal(1 << k) + 1j * rng.standard_normal(1 << k)) * 10.0 ** rng.integers(-30, 3, 1 << k)
+    special = np.array([0.0, -0.0, 1.0 + 2.0 ** -24, 1.0 + 3 * 2.0 ** -24, 1.0 - 2.0 ** -25, 2.0 ** -140, -2.0 ** -149,
+                        2.0 ** -150, 3.0e-39, 1.9999999999, 16777217.0, -16777219.0, 1e-46], dtype=np.float64)
+    psi[:len(special)] = special + 1j * special[::-1]
+    dev = DeviceChunk.from_numpy(psi)
+    want = psi.astype(np.complex64)
+    got = dev.download_c64()
+    assert got.dtype == np.complex64 and got.tobytes() == want.tobytes()
+    part = dev.download_c64(12345, 1000)
+    assert part.tobytes() == want[12345:13345].tobytes()
+    back = DeviceChunk.empty(k)
+    back.upload_c64(want)
+    assert back.download().tobytes() == want.astype(np.complex128).tobytes()
+    back.upload_c64(want[:64], offset=4096)
+    assert back.download(4096, 64).tobytes() == want[:64].astype(np.complex128).tobytes()
+    with pytest.raises(ValueError):
+        dev.download_c64((1 << k) - 10, 11)
+    dev.close()
+    back.close()
