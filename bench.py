@@ -155,7 +155,7 @@ def cpu_config1_columns() -> dict:
     return out
 
 
-def pmc_traffic_per_launch(kernel_prefix: str):
+def pmc_traffic_per_launch(kernel_prefix: str, local_qubits: int = 28):
     """(HBM bytes per launch of the dominant kernel, the summary it comes from) out of the committed rocprofv3 PMC
     passes (profiles/*_pmc_summary.json, written by tools/pmc_summary.py) -- but only from a summary taken with
     the kernel sources this run was built from (`csrc_sha16` == _lib.source_hash()); anything older is a stale
@@ -168,7 +168,7 @@ def pmc_traffic_per_launch(kernel_prefix: str):
             doc = json.loads(path.read_text())
         except Exception:
             continue
-        if doc.get("csrc_sha16") != now:
+        if doc.get("csrc_sha16") != now or doc.get("local_qubits", 28) != local_qubits:
             continue
         for row in doc.get("kernels", []):
             if row.get("kernel", "").startswith(kernel_prefix) and row.get("hbm_bytes_per_launch"):
@@ -257,7 +257,7 @@ def run_single(args, k: int) -> tuple[dict, list[str]]:
     if dom:
         secs = dom["total_ms"] * 1e-3
         moved = dom["hbm_bytes"] / secs / 1e9
-        traffic, traffic_source = pmc_traffic_per_launch(dom["kernel"].split(" ")[0])
+        traffic, traffic_source = pmc_traffic_per_launch(dom["kernel"].split(" ")[0], k)
         roofline = {"bound": "hbm", "achieved": round(moved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(moved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "traffic_source": traffic_source,
@@ -376,7 +376,7 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
         e1 = SingleGpuEngine(k, device=local_rank, mode=args.mode)
         c1 = gen.random_1q_cx_circuit(k, depth=args.depth)
         e1.init_zero_state()
-        reps1 = max(3, min(args.steps, 5))
+        reps1 = max(5, min(args.steps, 10))
         p1 = e1.plan(c1, repeats=2 + reps1)
         for _ in range(2):
             e1.execute(p1)
@@ -402,8 +402,9 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
     if dom:
         secs = dom["total_ms"] * 1e-3
         moved = dom["hbm_bytes"] / secs / 1e9
+        traffic, traffic_source = pmc_traffic_per_launch(dom["kernel"].split(" ")[0], k)   # a 1-GPU PMC run at this shard size
         roofline = {"bound": "hbm", "achieved": round(moved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(moved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(moved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": dom["kernel"], "launches": dom["launches"],
                     "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4),
                     "bytes_per_launch": dom["hbm_bytes"] / dom["launches"],

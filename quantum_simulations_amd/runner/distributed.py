@@ -714,12 +714,16 @@ class DistributedEngine:
         return out
 
     def comm_stats(self) -> dict:
-        ms = None
+        """Collective (every rank calls it): bytes and exchanges of this rank, device-side exchange time of this rank
+        and the maximum over all ranks (RCCL runs only: stream events around every exchange)."""
+        ms = ms_max = None
         if self._comm_events:
             self.backend.sync()
             ms = float(sum(a.elapsed_time(b) for a, b in self._comm_events))
+        if not self.dry and self.dist.is_initialized() and self.dist.get_backend() == "nccl":
+            ms_max = self.max_over_ranks(ms or 0.0)
         return {"bytes_sent_per_rank": self.xgmi_bytes_sent, "exchanges": self.exchanges,
-                "exchange_ms_rank0": ms}
+                "exchange_ms_rank0": ms, "exchange_ms_max_over_ranks": ms_max}
 
     def reset_comm_stats(self) -> None:
         self.xgmi_bytes_sent, self.exchanges, self._comm_events = 0, 0, []

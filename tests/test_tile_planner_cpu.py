@@ -330,3 +330,45 @@ def test_product_library_reads_no_planning_knobs():
     env.pop("QSIM_LIBRARY", None)
     out = subprocess.run([sys.executable, "-c", code], cwd=_ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "PASSES 18" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("n", [12, 14, 15])
+def test_commuting_ops_overtake_waiting_ones_correctly(n):
+    """Round 3's pass builder lets an op run a pass EARLIER than an op in front of it that has to wait, when the two are
+    diagonal (or both 1 / X) on every qubit they share.  Circuits made of exactly such neighbours -- fans of CNOTs from
+    one control, fans into one target, X on targets, Z / S / T / CZ / CR on controls, with a few Hadamards and dense
+    gates to end the runs -- on more qubits than a tile holds, so passes are cut in the middle of the runs."""
+    CNOT, CZ, H = orc.gate_matrix("CNOT"), orc.gate_matrix("CZ"), orc.gate_matrix("H")
+    for seed in range(8):
+        rng = np.random.default_rng(31000 + 97 * n + seed)
+        ops = []
+        for _ in range(60):
+            hub = int(rng.integers(n))
+            others = [int(q) for q in rng.permutation(n) if q != hub][:int(rng.integers(2, 6))]
+            kind = rng.random()
+            for q in others:
+                if kind < 0.35:
+                    ops.append(([hub, q], CNOT))                                   # common control
+                elif kind < 0.7:
+                    ops.append(([q, hub], CNOT))                                   # common target
+                elif kind < 0.85:
+                    ops.append(([hub, q], CZ if rng.random() < 0.5 else orc.gate_matrix("CR", {"k": int(rng.integers(2, 5))})))
+                else:
+                    ops.append(([q, hub], orc.gate_matrix("CY")))                  # Y on the target: NOT X-type
+                r = rng.random()
+                if r < 0.25:
+                    ops.append(([hub], orc.gate_matrix("X" if kind >= 0.35 and kind < 0.7 else "T")))
+                elif r < 0.35:
+                    ops.append(([q], orc.gate_matrix(("Z", "S", "X", "Y")[int(rng.integers(4))])))
+                elif r < 0.42:
+                    ops.append(([hub if rng.random() < 0.5 else q], H))
+                elif r < 0.45:
+                    a, b = (int(x) for x in rng.choice(n, size=2, replace=False))
+                    ops.append(([a, b], np.linalg.qr(rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4)))[0]))
+        psi = _rand_state(n, 40 + seed)
+        want = psi.copy()
+        orc.apply_ops(want, ops)
+        images = ti.plan(n, ops)
+        assert len(images) >= 2
+        ti.run(psi, images)
+        np.testing.assert_allclose(psi, want, rtol=0, atol=1e-12, err_msg=f"n={n} seed={seed}")

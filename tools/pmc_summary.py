@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 outputs into profiles/<tag>_*:
 
-    python tools/pmc_summary.py <tag> <trace_dir> <pmc_fetch_dir> <pmc_write_dir>
+    python tools/pmc_summary.py <tag> <trace_dir> <pmc_fetch_dir> <pmc_write_dir> [local_qubits of the profiled run, default 28]
 
   * <tag>_kernel_stats.csv   copy of rocprofv3 --kernel-trace --stats summary
   * <tag>_pmc_summary.json   per kernel class: launches, avg duration (from the stats pass),
@@ -52,6 +52,7 @@ def counter_avg(directory: str, counter: str):
 
 def main():
     tag, trace, fetch, write = sys.argv[1:5]
+    local_qubits = int(sys.argv[5]) if len(sys.argv) > 5 else 28
     prof = ROOT / "profiles"
     prof.mkdir(exist_ok=True)
     stats = glob.glob(f"{trace}/**/*_kernel_stats.csv", recursive=True)[0]
@@ -72,7 +73,7 @@ def main():
             row["write_size_KiB_avg"] = ws[k][1]
             row["hbm_bytes_per_launch"] = (2.0 * fs[k][1] + ws[k][1]) * 1024.0
         rows.append(row)
-    doc = {"tag": tag, "csrc_sha16": source_hash(), "source": "rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE "
+    doc = {"tag": tag, "csrc_sha16": source_hash(), "local_qubits": local_qubits, "source": "rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE; --pmc WRITE_SIZE "
                                  "(separate passes) on `python3 bench.py`",
            "correction": "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE = 1/2 of "
                          "wide coalesced reads; WRITE_SIZE exact for 16-B streaming stores)",
