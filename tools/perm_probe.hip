@@ -17,7 +17,8 @@
 //   lay    which tile bit (index into the sorted R) each in-tile position takes: 5 thread bits (3 lane, 2 wave), then the 3 bits of
 //          a thread's 8 accesses; default 0,1,...,7
 //   ro / wo  reads only / writes only (16 B per amplitude)
-//   order  0 consecutive tiles in flight, 1 XCD-contiguous (each XCD walks one eighth), 2 bit-reversed
+//   order  0 consecutive tiles in flight, 1 XCD-contiguous (each XCD walks one eighth), 2 bit-reversed,
+//          3 consecutive in the OUTPUT: the tile number counts the non-tile bits in the order of their output positions
 // Prints milliseconds per pass (median of 7) and TB/s moved (32 B per amplitude), and checks the result
 // against the permutation on sampled amplitudes.
 #include <hip/hip_runtime.h>
@@ -42,6 +43,7 @@ struct Args {
   unsigned char R[8];       // ascending tile bits (read layout)
   unsigned char lay[8];     // in-tile bit i (5 thread bits, then 3 element bits) -> index into R
   unsigned char pi[40];     // input bit -> output bit
+  unsigned char ord[40];    // order 3: the j-th bit of the tile number is input bit ord[j] (non-tile bits sorted by OUTPUT position)
 };
 
 // LDS: 0 none, 1 whole amplitudes (32 KiB: four workgroups per CU), 2 real and imaginary parts one after the other
@@ -57,10 +59,15 @@ __global__ __launch_bounds__(256, OCC) void k_move(const Args a) {
     if (a.order == 1) { const unsigned per = a.ntiles >> 3; const unsigned wg = blockIdx.x; tile = ((wg & 7) * (per / TPW) + (wg >> 3)) * TPW + i; }
     if (a.order == 2) tile = __brev(tile) >> (__clz(a.ntiles) + 1);
     u64 base = (u64)tile << 3;
+    if (a.order == 3) {
+      base = 0;
+      for (int j = 0; j < a.n - 11; ++j) base |= (u64)((tile >> j) & 1u) << a.ord[j];
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int p = a.R[j];
-      base = ((base >> p) << (p + 1)) | (base & ((1ull << p) - 1));
+      for (int j = 0; j < 8; ++j) {
+        const int p = a.R[j];
+        base = ((base >> p) << (p + 1)) | (base & ((1ull << p) - 1));
+      }
     }
     u64 o = 0;
     for (int b = 3; b < a.n; ++b) o |= ((base >> b) & 1ull) << a.pi[b];
@@ -202,6 +209,12 @@ int main(int argc, char** argv) {
     for (int b = 0; b < 3; ++b) if (a.pi[b] != b) ok = false;
     for (int i = 0; i < 8; ++i) if (a.R[i] < 3 || a.R[i] >= n || (i && a.R[i] == a.R[i - 1])) ok = false;
     if (!ok) { printf("bad spec: %s\n", argv[s]); continue; }
+    {   // order 3: non-tile input bits sorted by where they land in the output
+      std::vector<int> free_bits;
+      for (int b = 3; b < n; ++b) { bool t = false; for (int i = 0; i < 8; ++i) t = t || a.R[i] == b; if (!t) free_bits.push_back(b); }
+      std::sort(free_bits.begin(), free_bits.end(), [&](int x, int y) { return a.pi[x] < a.pi[y]; });
+      for (size_t j = 0; j < free_bits.size(); ++j) a.ord[j] = (unsigned char)free_bits[j];
+    }
     a.src = A;
     a.dst = inplace ? A : B;
     a.ntiles = (unsigned)(N >> 11);

@@ -20,5 +20,7 @@ for D in sets:
     specs.append(f"R={d};inplace;name=inplace        D={d}")
     specs.append(f"R={','.join(map(str, P))};P={swap};name=v1 read P* -> D  D={d}")
     specs.append(f"R={d};P={swap};name=v2 read D -> P*  D={d}")
+    specs.append(f"R={d};P={swap};order=3;name=v2 + output-ordered tiles D={d}")
+    specs.append(f"R={','.join(map(str, P))};P={swap};order=3;name=v1 + output-ordered tiles D={d}")
 exe = Path(__file__).resolve().parent / "perm_probe"
 subprocess.run([str(exe), str(n)] + specs, check=False)
