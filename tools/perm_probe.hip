@@ -16,6 +16,7 @@
 //   plain  1: plain loads, 2: plain stores, 3: both (default: non-temporal)
 //   lay    which tile bit (index into the sorted R) each in-tile position takes: 5 thread bits (3 lane, 2 wave), then the 3 bits of
 //          a thread's 8 accesses; default 0,1,...,7
+//   swz    software XOR swizzle of the addresses (both sides): a>b,... = physical bit b ^= index bit a (a > b, b >= 3)
 //   ro / wo  reads only / writes only (16 B per amplitude)
 //   order  0 consecutive tiles in flight, 1 XCD-contiguous (each XCD walks one eighth), 2 bit-reversed,
 //          3 consecutive in the OUTPUT: the tile number counts the non-tile bits in the order of their output positions
@@ -43,6 +44,8 @@ struct Args {
   unsigned char R[8];       // ascending tile bits (read layout)
   unsigned char lay[8];     // in-tile bit i (5 thread bits, then 3 element bits) -> index into R
   unsigned char pi[40];     // input bit -> output bit
+  unsigned char swz_src[8], swz_dst[8];   // software address swizzle: physical bit dst ^= index bit src (both sides)
+  int nswz;
   unsigned char ord[40];    // order 3: the j-th bit of the tile number is input bit ord[j] (non-tile bits sorted by OUTPUT position)
 };
 
@@ -92,21 +95,34 @@ __global__ __launch_bounds__(256, OCC) void k_move(const Args a) {
       jout[j] |= (u64)((j >> b) & 1) << a.pi[p];
     }
   }
+  auto swz = [&](u64 i) -> u64 {
+    u64 x = 0;
+    for (int t = 0; t < a.nswz; ++t) x |= ((i >> a.swz_src[t]) & 1ull) << a.swz_dst[t];
+    return i ^ x;
+  };
+  // (the swizzle is linear over XOR and the three parts of an index have disjoint bits: swizzle them separately)
+  const u64 stin = swz(tin), stout = swz(tout);
+  u64 sjin[8], sjout[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sjin[j] = swz(jin[j]); sjout[j] = swz(jout[j]); }
   u64 obase;
   u64 base = tile_base(0, &obase);
+  u64 sb = swz(base);
   amp_t v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = a.rw == 2 ? amp_t{1.0, 2.0} : ((a.plain & 1) ? *(gamp_t*)(a.src + base + tin + jin[j]) : __builtin_nontemporal_load((gamp_t*)(a.src + base + tin + jin[j])));
+  for (int j = 0; j < 8; ++j) v[j] = a.rw == 2 ? amp_t{1.0, 2.0} : ((a.plain & 1) ? *(gamp_t*)(a.src + (sb ^ stin ^ sjin[j])) : __builtin_nontemporal_load((gamp_t*)(a.src + (sb ^ stin ^ sjin[j]))));
 #pragma unroll 1
   for (int it = 0; it < TPW; ++it) {
     amp_t x[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = v[j];
     const u64 cur_out = obase;
+    const u64 scur = swz(cur_out);
     if (it + 1 < TPW) {
       base = tile_base(it + 1, &obase);
+      sb = swz(base);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = a.rw == 2 ? amp_t{1.0, 2.0} : ((a.plain & 1) ? *(gamp_t*)(a.src + base + tin + jin[j]) : __builtin_nontemporal_load((gamp_t*)(a.src + base + tin + jin[j])));
+      for (int j = 0; j < 8; ++j) v[j] = a.rw == 2 ? amp_t{1.0, 2.0} : ((a.plain & 1) ? *(gamp_t*)(a.src + (sb ^ stin ^ sjin[j])) : __builtin_nontemporal_load((gamp_t*)(a.src + (sb ^ stin ^ sjin[j]))));
     }
     if (LDS == 1) {
       amp_t* t = reinterpret_cast<amp_t*>(lds);
@@ -132,8 +148,8 @@ __global__ __launch_bounds__(256, OCC) void k_move(const Args a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (a.rw != 1 || x[j].x == -12345.678) {
-        if (a.plain & 2) *(gamp_t*)(a.dst + cur_out + tout + jout[j]) = x[j];
-        else __builtin_nontemporal_store(x[j], (gamp_t*)(a.dst + cur_out + tout + jout[j]));
+        if (a.plain & 2) *(gamp_t*)(a.dst + (scur ^ stout ^ sjout[j])) = x[j];
+        else __builtin_nontemporal_store(x[j], (gamp_t*)(a.dst + (scur ^ stout ^ sjout[j])));
       }
     if (LDS != 0 && it + 1 < TPW) __syncthreads();
   }
@@ -190,6 +206,15 @@ int main(int argc, char** argv) {
       } else if (part == "inplace") inplace = true;
       else if (part.rfind("tpw=", 0) == 0) tpw = atoi(part.c_str() + 4);
       else if (part.rfind("lds=", 0) == 0) lds = atoi(part.c_str() + 4);
+      else if (part.rfind("swz=", 0) == 0) {
+        for (const std::string& mv : split(part.substr(4), ',')) {
+          auto ab = split(mv, '>');
+          if (ab.size() != 2 || a.nswz >= 8) { ok = false; break; }
+          a.swz_src[a.nswz] = (unsigned char)atoi(ab[0].c_str());
+          a.swz_dst[a.nswz] = (unsigned char)atoi(ab[1].c_str());
+          ++a.nswz;
+        }
+      }
       else if (part.rfind("lay=", 0) == 0) {
         auto v = split(part.substr(4), ',');
         if (v.size() != 8) { ok = false; break; }
@@ -241,8 +266,10 @@ int main(int argc, char** argv) {
       u64 i = ((u64)rand() << 20 ^ (u64)rand()) & (N - 1), o = 0;
       for (int b = 0; b < n; ++b) o |= ((i >> b) & 1ull) << a.pi[b];
       double2 got;
+      { u64 x = 0; for (int t = 0; t < a.nswz; ++t) x |= ((o >> a.swz_src[t]) & 1ull) << a.swz_dst[t]; o ^= x; }
       CK(hipMemcpy(&got, a.dst + o, sizeof got, hipMemcpyDeviceToHost));
-      if (got.x != (double)i) ++bad;
+      u64 si = i; { u64 x = 0; for (int t = 0; t < a.nswz; ++t) x |= ((i >> a.swz_src[t]) & 1ull) << a.swz_dst[t]; si ^= x; }
+      if (got.x != (double)si) ++bad;
     }
     std::vector<float> ms;
     for (int r = 0; r < 7; ++r) {
