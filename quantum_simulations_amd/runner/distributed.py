@@ -483,9 +483,10 @@ class DistributedEngine:
     def relayout(self, pairs) -> None:
         """pairs: [[p_a, p_b], ...] each with exactly one local and one global physical bit.
 
-        Pipelined in `pieces` sub-ranges of every slab: while piece s is on the links, piece s+1 is
-        being packed and piece s-1 unpacked (the pack / unpack passes are 10-30 % of a re-layout's
-        time at 8 GPUs when run back to back)."""
+        Fused (the default, slab bits above the line bits): the queued local ops' last pass stores the slabs, one
+        grouped exchange of whole slabs, the next local pass loads them -- no pass of the shard outside the links.
+        Unfused: pack / exchange / unpack, pipelined in `pieces` sub-ranges of every slab (while piece s is on the
+        links, piece s+1 is being packed and piece s-1 unpacked)."""
         loc = [min(p) for p in pairs]
         glo = [max(p) for p in pairs]
         m = len(pairs)
@@ -514,12 +515,10 @@ class DistributedEngine:
                 self._passes += 1
                 if not self.dry:
                     recv[mine * slab:(mine + 1) * slab].copy_(send[mine * slab:(mine + 1) * slab])
+            # (whole slabs in ONE group: there is no pack / unpack left to overlap the pieces with, and fewer, larger
+            # messages are what the links like)
             timer = self._comm_timer(send)
-            posted = [self._post([(peer, send[d * slab + s * part:d * slab + (s + 1) * part],
-                                   recv[d * slab + s * part:d * slab + (s + 1) * part]) for d, peer in peers])
-                      for s in range(pieces)]
-            for work in posted:
-                self._finish(work)
+            self._finish(self._post([(peer, send[d * slab:(d + 1) * slab], recv[d * slab:(d + 1) * slab]) for d, peer in peers]))
             self._comm_done(timer)
             self._state_in = (rname, list(loc))
             return

@@ -84,12 +84,17 @@ def test_python_engine_posts_the_planned_transfers(world, k, pairs):
     from quantum_simulations_amd.runner.distributed import DistributedEngine, DryBackend
     n = k + world.bit_length() - 1
     for rank in range(world):
-        eng = DistributedEngine(n, world, rank, backend=DryBackend(k), init_process_group=False)
-        eng.relayout(pairs)
-        plan = relayout_plan(rank, world, k, [min(p) for p in pairs], [max(p) - k for p in pairs], eng.relayout_pieces)
-        posted = [(peer, sent // 16) for _, peer, sent, _ in eng.trace]
-        want = [(peer, plan["piece_amps"]) for _ in range(plan["pieces"]) for peer in plan["peers"]]
-        assert posted == want, (rank, posted[:8], want[:8])
+        for fuse in (False, True):
+            # unfused: the pack / transfer / unpack pipeline in pieces; fused (slab bits above the line bits): whole slabs
+            # in one group, like the plan with one piece
+            eng = DistributedEngine(n, world, rank, backend=DryBackend(k), init_process_group=False, fuse_relayout=fuse)
+            eng.relayout(pairs)
+            fused = fuse and min(min(p) for p in pairs) >= 3
+            plan = relayout_plan(rank, world, k, [min(p) for p in pairs], [max(p) - k for p in pairs],
+                                 1 if fused else eng.relayout_pieces)
+            posted = [(peer, sent // 16) for _, peer, sent, _ in eng.trace]
+            want = [(peer, plan["piece_amps"]) for _ in range(plan["pieces"]) for peer in plan["peers"]]
+            assert posted == want, (rank, fuse, posted[:8], want[:8])
 
 
 def test_bad_arguments():
