@@ -135,6 +135,11 @@ def test_world8_gloo():
     _run(8, 7, [(True, "belady"), (True, "heuristic"), (False, "heuristic"), (False, "heuristic", False)])
 
 
+def test_world8_gloo_larger_shards():
+    """8 ranks x 7 local qubits: three-qubit re-layouts (7/8 of a shard to seven peers) through the fused path."""
+    _run(8, 10, [(True, "belady"), (False, "heuristic")])
+
+
 def test_two_local_qubits_is_the_minimum():
     """k = 2 works (every dense global gate finds its victims), k < 2 is refused with a clear message."""
     _run(4, 4, [(False, "heuristic"), (True, "belady")])
