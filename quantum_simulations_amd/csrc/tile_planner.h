@@ -869,10 +869,29 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
   auto mask_of = [](const std::vector<int>& bits, size_t n) { u64 m = 0; for (size_t i = 0; i < n && i < bits.size(); ++i) m |= 1ull << bits[i]; return m; };
   // candidate tiles for the next pass from the current `done` / `first`: [0] = first come, then the
   // look-ahead ones grown from the first `seed` claimed bits
-  u64 forced = 0;                               // (probe) bits that every tile holds
-  for (int b = low; b < low + tune.plan_force_low && b < k && __builtin_popcountll(forced) < cap; ++b) forced |= 1ull << b;
-  const int n_forced = __builtin_popcountll(forced);
-  auto candidates = [&](std::vector<u64>* out, size_t max_seed, size_t seed_step) {
+  u64 forced_static = 0;                        // (probe) bits that every tile holds
+  for (int b = low; b < low + tune.plan_force_low && b < k && __builtin_popcountll(forced_static) < cap; ++b) forced_static |= 1ull << b;
+  // Anchored tiles (tuning().plan_anchor = s > 0, evaluation knob of round 4): every tile after the first shares at
+  // least s of its high bits with the tile of the pass before it (`prev`): those s qubits can stay on the physical
+  // positions next to the line bits (2^(s+7)-byte contiguous pieces per tile, the fast DRAM pattern) while the pass's
+  // store permutes the tile's qubits among the tile's positions.  The carried bits are grown greedily from the
+  // previous tile (the bit that lets the pass hold the most ops, one at a time).
+  const int anchor = tune.plan_anchor;
+  auto candidates = [&](std::vector<u64>* out, size_t max_seed, size_t seed_step, u64 prev) {
+    u64 forced = forced_static;
+    if (anchor > 0 && prev) {
+      for (int picked = 0; picked < anchor && picked < cap; ++picked) {
+        int pick = -1, pick_count = -(1 << 20);
+        for (int b = low; b < k; ++b) {
+          if (!((prev >> b) & 1) || ((forced >> b) & 1)) continue;
+          const int c = holds(forced | (1ull << b), nullptr);
+          if (c > pick_count) { pick_count = c; pick = b; }
+        }
+        if (pick < 0) break;
+        forced |= 1ull << pick;
+      }
+    }
+    const int n_forced = __builtin_popcountll(forced);
     std::vector<int> claimed;                   // high bits in the order they were claimed
     {
       u64 bt = 0, bd = 0, bx = 0, mask = forced;
@@ -909,9 +928,10 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
   const bool depth2 = tune.plan_lookahead >= 0 ? tune.plan_lookahead >= 2 : k >= 26;
   std::vector<u64> cands, cands2;
   std::vector<size_t> trial;
+  u64 prev_mask = 0;                            // high bits of the pass before (anchored tiles)
   while (remaining) {
     while (first < n_ops && done[first]) ++first;
-    candidates(&cands, 6, 2);
+    candidates(&cands, 6, 2, prev_mask);
     u64 best_mask = cands[0];
     int best_score = -(1 << 20);
     for (size_t ci = 0; ci < cands.size(); ++ci) {
@@ -922,7 +942,7 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
         const size_t first_saved = first;
         for (size_t i : trial) done[i] = 1;
         while (first < n_ops && done[first]) ++first;
-        candidates(&cands2, 4, 4);
+        candidates(&cands2, 4, 4, cands[ci]);
         int next_best = 0;
         for (u64 m2 : cands2) next_best = std::max(next_best, std::min(holds(m2, nullptr), kSaturated) - penalty(m2));
         for (size_t i : trial) done[i] = 0;
@@ -943,6 +963,8 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
     for (int b = low; (int)high.size() < cap && b < k; ++b)
       if (std::find(high.begin(), high.end(), b) == high.end()) high.push_back(b);   // (bits 3.. conflict with nothing)
     std::sort(high.begin(), high.end());
+    prev_mask = 0;
+    for (int b : high) prev_mask |= 1ull << b;
 #ifdef QSIM_PROBES
     if (tune.debug_skip_gates == 2) for (int j = 0; j < cap; ++j) high[j] = low + j;   // contiguous tiles (floor probe)
     if (tune.debug_skip_gates == 3) for (int j = 0; j < cap; ++j) high[j] = k - cap + j; // far-strided tiles
