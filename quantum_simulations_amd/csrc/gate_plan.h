@@ -50,6 +50,7 @@ struct Tuning {
   int plan_jitter = 0;       // probe: > 0 seeds pseudo-random tie-breaks (and losses of up to two ops) in the pass builder's growth choices
   int plan_force_low = 0;    // probe: the lowest N index bits above the line bits (3 .. 3 + N - 1) are tile bits of EVERY pass (2^(N+7)-byte
                              // contiguous pieces per tile: full DRAM rows on the write side, profiles/r03e_perm_windows_28q.txt)
+  int plan_scan_window = 384; // pass builder: ops (not yet done) behind the first waiting op that a pass may take its ops from (bounds the host time per pass on long lists)
   int plan_anchor = 0;       // probe (round 4 evaluation): every tile shares >= N high bits with the tile of the pass before it
   int tile_sink_swaps = 1;   // X / CNOT that nothing later in their group touches: swap LDS addresses at write-back (OPC_ASWAP1)
   int tile_group_search = 1; // register groups: try every triple of pending target bits, not only first come
@@ -80,6 +81,7 @@ struct Tuning {
     if (const char* e = getenv("QSIM_PLAN_COMMUTE")) plan_commute = atoi(e);
     if (const char* e = getenv("QSIM_PLAN_JITTER")) plan_jitter = atoi(e);
     if (const char* e = getenv("QSIM_PLAN_FORCE_LOW")) plan_force_low = std::max(0, std::min(6, atoi(e)));
+    if (const char* e = getenv("QSIM_PLAN_SCAN_WINDOW")) plan_scan_window = std::max(1, atoi(e));
     if (const char* e = getenv("QSIM_PLAN_ANCHOR")) plan_anchor = std::max(0, std::min(7, atoi(e)));
     if (const char* e = getenv("QSIM_TILE_MUX")) tile_mux = atoi(e);
     if (const char* e = getenv("QSIM_TILE_COMMUTE_FUSE")) tile_commute_fuse = atoi(e);

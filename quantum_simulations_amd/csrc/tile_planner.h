@@ -823,12 +823,22 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
   size_t remaining = n_ops;
   size_t first = 0;
   *n_passes = 0;
+  // How far behind `first` a pass looks for ops (counted in ops not yet done).  The scans below end early once every
+  // qubit is blocked for everything (`bt`), which never happens while some qubit is used only as a control, phase bit or
+  // X target (a GHZ root, a phase-estimation ancilla, an idle qubit): every scan then walked the whole remaining list --
+  // 12 ms of host planning per pass on a 4000-op list, several times the device time of the pass.  An op
+  // that far behind the front has a few thousand waiting ops on at most 35 qubits in front of it and is admissible only
+  // by accident; it runs a pass later.  Lists shorter than the window (the bench circuits, QFT(33)) plan as before.
+  // (byte-identical plans to the unbounded scan on the 28- / 30-qubit bench and Clifford+T circuits from 384 on; lists
+  // of more than four windows use two thirds of it: 7.5 -> 1.4 ms per pass on a 4000-op list with a control-only qubit)
+  int scan_window = tune.plan_scan_window;
   // ops a pass with the given high bits would hold (optionally listed)
   auto holds = [&](u64 tile_mask, std::vector<size_t>* out) -> int {
     u64 bt = 0, bd = 0, bx = 0;
-    int count = 0;
+    int count = 0, seen = 0;
     for (size_t i = first; i < n_ops && count < tune.max_gates_per_pass; ++i) {
       if (done[i]) continue;
+      if (++seen > scan_window) break;
       if (!admissible3(i, bt, bd, bx) || (need[i] & ~tile_mask)) {
         bt |= tm[i] & ~xm[i];
         bx |= xm[i];
@@ -895,9 +905,10 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
     std::vector<int> claimed;                   // high bits in the order they were claimed
     {
       u64 bt = 0, bd = 0, bx = 0, mask = forced;
-      int count = 0;
+      int count = 0, seen = 0;
       for (size_t i = first; i < n_ops && count < tune.max_gates_per_pass; ++i) {
         if (done[i]) continue;
+        if (++seen > scan_window) break;
         bool ok = admissible3(i, bt, bd, bx);
         const u64 extra = need[i] & ~mask;
         if (ok && n_forced + (int)claimed.size() + __builtin_popcountll(extra) > cap) ok = false;
@@ -931,6 +942,7 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
   u64 prev_mask = 0;                            // high bits of the pass before (anchored tiles)
   while (remaining) {
     while (first < n_ops && done[first]) ++first;
+    scan_window = remaining > 4 * (size_t)tune.plan_scan_window ? std::max(1, tune.plan_scan_window * 2 / 3) : tune.plan_scan_window;
     candidates(&cands, 6, 2, prev_mask);
     u64 best_mask = cands[0];
     int best_score = -(1 << 20);

@@ -304,7 +304,8 @@ _KNOBS = [("QSIM_PASS_GATES", v) for v in ("1", "7", "40")] + [("QSIM_PLAN_LOOKA
                              "QSIM_TILE_SINK_SWAPS", "QSIM_TILE_DIRECT", "QSIM_TILE_MUX", "QSIM_TILE_LAST_SEARCH",
                              "QSIM_PLAN_CONFLICT_COST", "QSIM_PLAN_COMMUTE")] + \
          [("QSIM_PLAN_CONFLICT_COST", "3"), ("QSIM_PLAN_COMMUTE", "1"), ("QSIM_TILE_COMMUTE_FUSE", "1"), ("QSIM_TILE_COMMUTE_FUSE", "2"),
-          ("QSIM_TILE_COMMUTE_FUSE", "3"), ("QSIM_TILE_COMMUTE_FUSE", "4"), ("QSIM_TILE_LAST_SEARCH", "3")]
+          ("QSIM_TILE_COMMUTE_FUSE", "3"), ("QSIM_TILE_COMMUTE_FUSE", "4"), ("QSIM_TILE_LAST_SEARCH", "3"),
+          ("QSIM_PLAN_SCAN_WINDOW", "1"), ("QSIM_PLAN_SCAN_WINDOW", "24"), ("QSIM_PLAN_ANCHOR", "3"), ("QSIM_PLAN_ANCHOR", "6")]
 
 
 @pytest.mark.parametrize("knob,value", _KNOBS)
@@ -372,3 +373,59 @@ def test_commuting_ops_overtake_waiting_ones_correctly(n):
         assert len(images) >= 2
         ti.run(psi, images)
         np.testing.assert_allclose(psi, want, rtol=0, atol=1e-12, err_msg=f"n={n} seed={seed}")
+
+
+def _long_list_with_a_control_only_qubit(n: int, n_ops: int, seed: int) -> list:
+    """Qubit 0 is only ever a CNOT control: the pass builder's "every qubit is blocked" early exit never fires."""
+    rng = np.random.default_rng(seed)
+    H, T, CX = orc.gate_matrix("H"), orc.gate_matrix("T"), orc.gate_matrix("CNOT")
+    ops = []
+    for _ in range(n_ops):
+        r = rng.random()
+        if r < 0.5:
+            ops.append(([int(rng.integers(1, n))], H if rng.random() < 0.5 else T))
+        elif r < 0.6:
+            ops.append(([0, int(rng.integers(1, n))], CX))
+        else:
+            a, b = (int(x) for x in rng.choice(np.arange(1, n), size=2, replace=False))
+            ops.append(([a, b], CX))
+    return ops
+
+
+def test_planning_time_per_pass_is_bounded_on_long_lists():
+    """with a control-only qubit every scan of the commutation-aware pass builder walked the whole remaining
+    list -- 7.5-12 ms of host time per pass on a 4000-op list, several times the device time of a 28-qubit pass (1.7 ms).
+    The scans now stop `plan_scan_window` waiting ops behind the front (csrc/tile_planner.h).  Budget: 4 ms per pass
+    (measured 1.4-1.6 ms on the build container) -- and no more passes than the unbounded scan needed (100)."""
+    import ctypes as C
+    import time
+
+    from quantum_simulations_amd import _lib
+    from quantum_simulations_amd.kernel.device import pack_ops
+    if os.environ.get("QSIM_PLANNER_CHILD"):
+        pytest.skip("pass count and budget are those of the default planner, not of a forced look-ahead setting")
+    n = 28
+    nq, qubits, mats = pack_ops(_long_list_with_a_control_only_qubit(n, 4000, 1))
+    lib = _lib.load()
+    k = C.c_int32()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        _lib.check(lib.qsim_plan_ops(n, len(nq), nq.ctypes.data_as(C.c_void_p), qubits.ctypes.data_as(C.c_void_p),
+                                     mats.ctypes.data_as(C.c_void_p), None, 0, C.byref(k)))
+        best = min(best, time.perf_counter() - t0)
+    assert k.value <= 102, k.value
+    assert best / k.value < 4e-3, f"{best / k.value * 1e3:.2f} ms of planning per pass"
+
+
+def test_bounded_scan_plans_equal_the_oracle_on_lists_longer_than_the_window():
+    """Op lists of several scan windows (default 384 waiting ops) on 13 qubits, control-only qubit included: planned,
+    interpreted, compared with the oracle."""
+    n = 13
+    for seed in (5, 6):
+        ops = _long_list_with_a_control_only_qubit(n, 2500, seed)
+        psi = _rand_state(n, 900 + seed)
+        want = psi.copy()
+        orc.apply_ops(want, ops)
+        ti.run(psi, ti.plan(n, ops))
+        np.testing.assert_allclose(psi, want, rtol=0, atol=1e-11)
