@@ -3,9 +3,16 @@
 path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          # N > 1 without a launcher: this process starts its N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run ... bench.py --gpus N --dry-run     # comm schedule only (gloo, no shards)
+    python bench.py --gpus N --dry-run                     # comm schedule only (gloo, no shards, no GPU)
+    python bench.py --gpus 4 --rehearsal --local-qubits 24 # N ranks sharing the visible GPU(s), host-staged gloo exchange
+
+Started without WORLD_SIZE in the environment, `--gpus N > 1` makes this process the PARENT of N fresh rank processes
+(one per GPU, 127.0.0.1 rendezvous on a free port -- the per-chunk task fan-out of the reference's
+runner/spark_runner.py:128-136 with one long-lived task per shard).  The parent never touches the GPU, relays rank 0's
+single JSON line, and exits non-zero if any rank does, ending the others instead of waiting for them.
 
 Workload: the seeded random 1q+CX circuit, depth 40 (BASELINE configs[1]).  N = 1: 28 qubits (4 GiB,
 the configuration the metric is quoted on).  N > 1: 30 LOCAL qubits per GPU (16 GiB shards, weak
@@ -33,7 +40,7 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 PARITY_TOL = 1e-10
 NORM_TOL = 1e-9
-ALLOWED_ENV = {"QSIM_DIST_BACKEND"}      # rehearsal switch of the distributed engine (gloo on one GPU)
+ALLOWED_ENV: set = set()                 # no QSIM_* variable is read by anything this script times
 
 
 def parse_args():
@@ -58,6 +65,14 @@ def parse_args():
                     help="N > 1: skip the one-GPU run at the same local size on rank 0")
     ap.add_argument("--dry-run", action="store_true",
                     help="N > 1: print and cross-check the communication schedule only (gloo, no shard memory)")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="N > 1: the ranks share the visible GPU(s) and exchange through host-staged gloo (RCCL refuses two "
+                         "ranks on one device); the line says \"exchange\": \"gloo-rehearsal\" and is not a multi-GPU number")
+    ap.add_argument("--exchange", choices=["torch", "cabi"], default="torch",
+                    help="N > 1: who posts the RCCL transfers: torch.distributed P2P (default) or the library's own "
+                         "communicator (qsim_comm_exchange, C ABI)")
+    ap.add_argument("--no-amplitude-check", action="store_true",
+                    help="N > 1: skip the one-GPU reference runs behind the per-shard fingerprint comparison")
     return ap.parse_args()
 
 
@@ -337,7 +352,7 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
     n = k + p
     circuit = gen.random_1q_cx_circuit(n, depth=args.depth)
     n_gates = len(circuit["gates"])
-    engine = make_engine(n, world, rank, local_rank, mode=args.mode)
+    engine = make_engine(n, world, rank, local_rank, mode=args.mode, rehearsal=args.rehearsal, exchange=args.exchange)
     engine.init_zero_state()
     plan = engine.plan(circuit, repeats=args.warmup + args.steps)
     for _ in range(args.warmup):
@@ -360,13 +375,23 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
 
     configs = None
     if not args.no_configs:
-        configs = engine.run_baseline_configs(gen)          # config 4 staged / unstaged, config 5 closed forms
+        # config 5 closed forms; config 4 staged / unstaged and the random 1q+CX circuit: every amplitude, through
+        # per-shard fingerprints, against a one-GPU run of the same circuit on rank 0
+        configs = engine.run_baseline_configs(gen, check_amplitudes=not args.no_amplitude_check)
         for rec in configs.get("config5", []):
             if not rec["max_abs_err_vs_closed_form"] < PARITY_TOL:
                 invalid.append(f"config 5 {rec['circuit']}: max error {rec['max_abs_err_vs_closed_form']:.3e}")
-        c4 = configs.get("config4")
-        if c4 and abs(c4["staged"]["norm2"] - 1.0) > NORM_TOL:
-            invalid.append("config 4: norm check failed")
+        for key in ("config4", "random_1q_cx"):
+            rec = configs.get(key) or {}
+            for label in ("staged", "unstaged"):
+                run = rec.get(label)
+                if not run:
+                    continue
+                if abs(run["norm2"] - 1.0) > NORM_TOL:
+                    invalid.append(f"{key} {label}: norm check failed")
+                d = run.get("fingerprint_max_abs_diff_vs_single_gpu")
+                if d is not None and not d < PARITY_TOL:
+                    invalid.append(f"{key} {label}: shard fingerprints differ from the one-GPU run by {d:.3e} > {PARITY_TOL}")
     # the same workload family on ONE GPU at the same local size (rank 0, outside the timed region, the other
     # ranks wait): per-GPU work is what weak scaling holds fixed, and the N = 1 default of this script is the
     # 28-qubit metric configuration, not a 30-local-qubit one
@@ -417,6 +442,11 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
         "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
+        # what carried the transfers of this line: "rccl" (one rank per GPU over xGMI) or "gloo-rehearsal" (ranks sharing
+        # the visible GPUs, host-staged: NOT a multi-GPU number); exchange_api: who posts them (torch P2P / the C ABI)
+        "exchange": engine.exchange, "exchange_api": engine.exchange_api,
+        "exchange_ms_per_step_max_over_ranks": (round(xgmi["exchange_ms_max_over_ranks"] / args.steps, 3)
+                                                if xgmi.get("exchange_ms_max_over_ranks") is not None else None),
         "config": {"workload": f"{n}-qubit random 1q+CX circuit depth {args.depth} (seed 20260228), "
                                f"{n_gates} gates, complex128, {k} local qubits per GPU, shards = high qubits",
                    "n_qubits": n, "local_qubits": k, "gates_per_step": n_gates, "mode": args.mode,
@@ -440,18 +470,97 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
     return out, invalid
 
 
+# ---------------------------------------------------------------------------------- launcher-free N > 1
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks from here.
+
+    The parent (this process) makes NO GPU call -- no torch import, no library load -- picks a free port, starts N fresh
+    interpreters of this script (never exec: each child is a new process that initialises its own GPU), relays what rank 0
+    prints, and watches all of them: the first rank that exits non-zero ends the run -- the others are terminated (then
+    killed) instead of being waited for in a rendezvous or a collective that can no longer complete -- and the parent exits
+    with that rank's code.  Nothing is restarted.  Children die with the parent (PR_SET_PDEATHSIG)."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+
+    def die_with_parent():
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGKILL)       # PR_SET_PDEATHSIG
+        except Exception:
+            pass
+
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_RANKS_STARTED_BY="bench.py")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, preexec_fn=die_with_parent))
+
+    def relay(pipe):
+        # rank 0's JSON line(s) go to stdout; whatever else a library prints there (gloo's connection banner) to stderr
+        for line in iter(pipe.readline, b""):
+            out = sys.stdout.buffer if line.lstrip().startswith(b"{") else sys.stderr.buffer
+            out.write(line)
+            out.flush()
+
+    relay_thread = threading.Thread(target=relay, args=(procs[0].stdout,), daemon=True)
+    relay_thread.start()
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+
+    def on_signal(signum, _frame):
+        stop_all()
+        sys.exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, on_signal)
+    signal.signal(signal.SIGINT, on_signal)
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            r, rc = bad[0]
+            print(f"bench.py: rank {r} exited with code {rc}; stopping the other ranks", file=sys.stderr, flush=True)
+            stop_all()
+            rc = rc if rc > 0 else 1
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.1)
+    relay_thread.join(5.0)
+    return rc
+
+
 def main():
     args = parse_args()
     refuse_probe_environment()
+    if args.gpus < 1 or args.gpus & (args.gpus - 1):
+        raise SystemExit("number of GPUs must be a power of two (shards are indexed by high qubits)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    if world & (world - 1):
-        raise SystemExit("number of GPUs must be a power of two (shards are indexed by high qubits)")
+    fail_rank = os.environ.get("BENCH_TEST_FAIL_RANK")          # (tests/test_bench_launcher.py: a rank that dies at start)
+    if fail_rank is not None and int(fail_rank) == rank:
+        sys.exit(3)
     k = args.local_qubits or (28 if world == 1 else 30)
 
     if args.dry_run:

@@ -228,6 +228,16 @@ int qsim_max_abs_err_closed_form(qsim_chunk* c, int kind, int n_total_qubits,
 int qsim_max_abs_err_closed_form_perm(qsim_chunk* c, int kind, int n_total_qubits,
                                       uint64_t base_index, const int32_t* log_to_phys,
                                       double* out);
+/* Layout-aware fingerprint of a (partitioned, staged) state, evaluated on the device:
+ *     out = sum over the chunk's amplitudes i whose LOGICAL index y passes (y & sel_mask) == sel_value of amp_i * w(y)
+ * with y = the logical index of physical index base_index + i under log_to_phys (NULL = identity; the layout of
+ * atlas_stages / permute_state, staging.py:587-658) and w(y) a counter-based pseudo-random complex weight: a = mix(y ^
+ * mix(seed)), b = mix(a) (mix = one splitmix64 round), w = ((a >> 11) 2^-52 - 1) + i ((b >> 11) 2^-52 - 1).  The same
+ * amplitudes give the same sum (up to summation order) wherever they live: shard g of a multi-GPU run in its staged
+ * layout against the same index set of a one-GPU run of the circuit (ref_dense.simulate order, ref_dense.py:44-57)
+ * selected with sel_mask / sel_value -- an amplitude-level check of states too large to gather (n = 33: 128 GiB). */
+int qsim_fingerprint(qsim_chunk* c, int n_total_qubits, uint64_t base_index, const int32_t* log_to_phys, uint64_t seed,
+                     uint64_t sel_mask, uint64_t sel_value, double out[2]);
 int qsim_time_begin(qsim_chunk* c);                        /* hipEventRecord on stream  */
 int qsim_time_end(qsim_chunk* c, float* elapsed_ms);       /* record + synchronize      */
 

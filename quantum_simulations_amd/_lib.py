@@ -90,6 +90,7 @@ SIGNATURES = {
                                                C.POINTER(C.c_double)]),
     "qsim_max_abs_err_closed_form_perm": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64, _P,
                                                     C.POINTER(C.c_double)]),
+    "qsim_fingerprint": (C.c_int, [_P, C.c_int, C.c_uint64, _P, C.c_uint64, C.c_uint64, C.c_uint64, _P]),
     "qsim_time_begin": (C.c_int, [_P]),
     "qsim_time_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "qsim_profile_begin": (C.c_int, [_P]),

@@ -277,6 +277,49 @@ __global__ __launch_bounds__(kBlock) void k_closed_form_err(const double2* p, u6
   block_reduce_store<true>(worst, partial);
 }
 
+// ---- layout-aware fingerprint of a (partitioned, staged) state: sum_i amp_i * w(y_i) over the chunk's amplitudes whose
+// LOGICAL index y_i passes the filter (y & sel_mask) == sel_value, with counter-based pseudo-random complex weights of y
+// (two rounds of splitmix64 over y ^ mix(seed); real and imaginary part uniform in [-1, 1), exactly representable).
+// A state that is right up to rounding gives the same value wherever its amplitudes live: a shard of a multi-GPU run in
+// its staged layout, or the same index set of a one-GPU run (ref_dense.simulate semantics, ref_dense.py:44-57; layout
+// permute_state, staging.py:639-658).  Slabs that trade places, a wrong permutation or a lost phase change it at O(1).
+__host__ __device__ __forceinline__ u64 fp_mix(u64 x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(kBlock) void k_fingerprint(const double2* p, u64 n, int n_total, u64 base, u64 seed_mix,
+                                                        u64 sel_mask, u64 sel_value, double* partial, const BitPerm perm) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  double sr = 0.0, si = 0.0;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    u64 y = base + i;
+    if (perm.active) {
+      const u64 x = y;
+      y = 0;
+      for (int b = 0; b < n_total; ++b) y |= ((x >> b) & 1ull) << perm.to_logical[b];
+    }
+    if ((y & sel_mask) != sel_value) continue;
+    const u64 a = fp_mix(y ^ seed_mix), b2 = fp_mix(a);
+    const double wr = (double)(a >> 11) * 0x1p-52 - 1.0, wi = (double)(b2 >> 11) * 0x1p-52 - 1.0;
+    const double2 v = p[i];
+    sr += v.x * wr - v.y * wi;
+    si += v.x * wi + v.y * wr;
+  }
+  __shared__ double part[2 * (kBlock / 64)];
+  sr = wave_sum(sr);
+  si = wave_sum(si);
+  if ((threadIdx.x & 63) == 0) { part[2 * (threadIdx.x >> 6)] = sr; part[2 * (threadIdx.x >> 6) + 1] = si; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = 0.0, im = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) { r += part[2 * w]; im += part[2 * w + 1]; }
+    partial[2 * blockIdx.x] = r;
+    partial[2 * blockIdx.x + 1] = im;
+  }
+}
+
 static int ensure_scratch(qsim_chunk* c) {
   if (!c->scratch) {
     HIP_TRY(hipSetDevice(c->device));

@@ -932,6 +932,7 @@ int qsim_sync(qsim_chunk* c) {
 
 int qsim_max_abs_err_closed_form_perm(qsim_chunk* c, int kind, int n_total_qubits, uint64_t base_index,
                                       const int32_t* log_to_phys, double* out);
+static int bit_perm_from(const int32_t* log_to_phys, int n_total_qubits, BitPerm* perm, const char* what);
 
 int qsim_max_abs_err_closed_form(qsim_chunk* c, int kind, int n_total_qubits, uint64_t base_index, double* out) {
   return qsim_max_abs_err_closed_form_perm(c, kind, n_total_qubits, base_index, nullptr, out);
@@ -944,18 +945,7 @@ int qsim_max_abs_err_closed_form_perm(qsim_chunk* c, int kind, int n_total_qubit
   if (!out || (kind != 0 && kind != 1) || n_total_qubits < c->k || n_total_qubits > 52)
     return fail(QSIM_ERR_INVALID, "qsim_max_abs_err_closed_form: bad arguments");
   BitPerm perm;
-  std::memset(&perm, 0, sizeof perm);
-  if (log_to_phys) {
-    u64 seen = 0;
-    for (int q = 0; q < n_total_qubits; ++q) {
-      const int ph = log_to_phys[q];
-      if (ph < 0 || ph >= n_total_qubits || (seen >> ph) & 1)
-        return fail(QSIM_ERR_INVALID, "qsim_max_abs_err_closed_form: log_to_phys is not a permutation");
-      seen |= 1ull << ph;
-      perm.to_logical[ph] = (unsigned char)q;
-      if (ph != q) perm.active = 1;
-    }
-  }
+  if ((rc = bit_perm_from(log_to_phys, n_total_qubits, &perm, "qsim_max_abs_err_closed_form"))) return rc;
   if ((rc = ensure_scratch(c))) return rc;
   HIP_TRY(hipSetDevice(c->device));
   const unsigned grid = std::min<unsigned>(stream_grid(amps(c)), kReduceBlocks);
@@ -968,6 +958,47 @@ int qsim_max_abs_err_closed_form_perm(qsim_chunk* c, int kind, int n_total_qubit
   double worst = 0;
   for (double v : host) worst = std::max(worst, v);
   *out = worst;
+  return QSIM_OK;
+}
+
+static int bit_perm_from(const int32_t* log_to_phys, int n_total_qubits, BitPerm* perm, const char* what) {
+  std::memset(perm, 0, sizeof *perm);
+  if (!log_to_phys) return QSIM_OK;
+  u64 seen = 0;
+  for (int q = 0; q < n_total_qubits; ++q) {
+    const int ph = log_to_phys[q];
+    if (ph < 0 || ph >= n_total_qubits || (seen >> ph) & 1) return fail(QSIM_ERR_INVALID, "%s: log_to_phys is not a permutation", what);
+    seen |= 1ull << ph;
+    perm->to_logical[ph] = (unsigned char)q;
+    if (ph != q) perm->active = 1;
+  }
+  return QSIM_OK;
+}
+
+// sum over the chunk's amplitudes whose logical index passes the filter of amp * w(logical index): see k_fingerprint
+int qsim_fingerprint(qsim_chunk* c, int n_total_qubits, uint64_t base_index, const int32_t* log_to_phys, uint64_t seed,
+                     uint64_t sel_mask, uint64_t sel_value, double out[2]) {
+  int rc = check_chunk(c, "qsim_fingerprint");
+  if (rc) return rc;
+  if (!out || n_total_qubits < c->k || n_total_qubits > 52) return fail(QSIM_ERR_INVALID, "qsim_fingerprint: bad arguments");
+  if (base_index & (amps(c) - 1)) return fail(QSIM_ERR_INVALID, "qsim_fingerprint: base_index must be a multiple of the chunk length");
+  if (n_total_qubits < 64 && ((base_index + amps(c) - 1) >> n_total_qubits)) return fail(QSIM_ERR_INVALID, "qsim_fingerprint: the chunk does not fit a state of %d qubits at that base", n_total_qubits);
+  if (sel_value & ~sel_mask) return fail(QSIM_ERR_INVALID, "qsim_fingerprint: sel_value has bits outside sel_mask");
+  BitPerm perm;
+  if ((rc = bit_perm_from(log_to_phys, n_total_qubits, &perm, "qsim_fingerprint"))) return rc;
+  if ((rc = ensure_scratch(c))) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  const unsigned grid = std::min<unsigned>(stream_grid(amps(c)), kReduceBlocks / 2);
+  hipLaunchKernelGGL(k_fingerprint, dim3(grid), dim3(kBlock), 0, c->stream, c->amp, amps(c), n_total_qubits, (u64)base_index,
+                     fp_mix((u64)seed), (u64)sel_mask, (u64)sel_value, c->scratch, perm);
+  HIP_TRY(hipGetLastError());
+  std::vector<double> host(2 * (size_t)grid);
+  HIP_TRY(hipMemcpyAsync(host.data(), c->scratch, sizeof(double) * host.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  long double re = 0, im = 0;
+  for (unsigned b = 0; b < grid; ++b) { re += host[2 * b]; im += host[2 * b + 1]; }
+  out[0] = (double)re;
+  out[1] = (double)im;
   return QSIM_OK;
 }
 

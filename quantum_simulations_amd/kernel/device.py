@@ -224,6 +224,17 @@ class DeviceChunk:
             None if perm is None else perm.ctypes.data_as(C.c_void_p), C.byref(out)))
         return out.value
 
+    def fingerprint(self, n_total: int, base_index: int = 0, log_to_phys=None, seed: int = 0,
+                    sel_mask: int = 0, sel_value: int = 0) -> complex:
+        """sum of amp * w(logical index) over this chunk's amplitudes whose logical index y has (y & sel_mask) ==
+        sel_value (qsim_fingerprint: counter-based weights, layout-aware, evaluated on the device)."""
+        out = (C.c_double * 2)()
+        perm = None if log_to_phys is None else np.asarray(log_to_phys, dtype=np.int32)
+        _lib.check(_lib.load().qsim_fingerprint(
+            self._h, n_total, base_index, None if perm is None else perm.ctypes.data_as(C.c_void_p),
+            seed, sel_mask, sel_value, out))
+        return complex(out[0], out[1])
+
     def time_begin(self) -> None:
         _lib.check(_lib.load().qsim_time_begin(self._h))
 

@@ -118,6 +118,18 @@ class HipShardBackend:
     def closed_form_error(self, kind: str, n_total: int, base_index: int, log_to_phys) -> float:
         return self.chunk("state").max_abs_err_closed_form(kind, n_total, base_index, log_to_phys)
 
+    def fingerprint(self, n_total: int, base_index: int, log_to_phys, seed: int, sel_mask: int = 0, sel_value: int = 0) -> complex:
+        return self.chunk("state").fingerprint(n_total, base_index, log_to_phys, seed, sel_mask, sel_value)
+
+    def release_buffers(self) -> None:
+        """Give the exchange buffers back to the device (they are re-created on demand): room for a one-GPU reference
+        run of the whole state next to the shard."""
+        self.sync()
+        for name in [n for n in self._tensors if n != "state"]:
+            self._chunks.pop(name).close()
+            del self._tensors[name]
+        self.torch.cuda.empty_cache()
+
     def profile_begin(self) -> None:
         self.chunk("state").profile_begin()
 
@@ -207,7 +219,8 @@ class DistributedEngine:
     def __init__(self, n_qubits: int, world: int, rank: int, local_rank: int = 0,
                  mode: str = "fused", backend=None, staging: bool = True,
                  staging_method: str = "belady", init_process_group: bool = True,
-                 relayout_pieces: int = 4, min_piece_qubits: int = 20, fuse_relayout: bool = True):
+                 relayout_pieces: int = 4, min_piece_qubits: int = 20, fuse_relayout: bool = True,
+                 rehearsal: bool = False, exchange: str = "torch"):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -222,8 +235,10 @@ class DistributedEngine:
             raise ValueError(f"{n_qubits} qubits on {world} ranks leave {max(self.k, 0)} local qubit(s): at least 2 are needed "
                              "(use fewer ranks)")
         self.mode, self.staging, self.staging_method = mode, staging, staging_method
-        import os
-        rehearsal = backend is None and os.environ.get("QSIM_DIST_BACKEND") == "gloo"
+        # rehearsal (explicit argument; bench.py --rehearsal): several ranks share the visible GPU(s), each with its shard
+        # in HBM and the real HIP kernels, and exchange through host-staged gloo -- RCCL refuses two ranks on one
+        # device.  `self.exchange` names what carries the transfers and is printed in every bench line.
+        rehearsal = bool(rehearsal) and backend is None
         if backend is None:
             if rehearsal:   # several ranks share the visible GPU(s); exchange is host-staged over gloo
                 local_rank = local_rank % max(1, torch.cuda.device_count())
@@ -234,6 +249,10 @@ class DistributedEngine:
                                         device_id=torch.device(f"cuda:{local_rank}"))
             else:
                 dist.init_process_group("gloo", rank=rank, world_size=world)
+        if exchange not in ("torch", "cabi"):
+            raise ValueError("exchange must be 'torch' (torch.distributed P2P) or 'cabi' (qsim_comm_exchange)")
+        self.exchange_api = exchange
+        self.exchange = "gloo-rehearsal" if rehearsal else ("rccl" if backend is None else f"gloo ({type(backend).__name__})")
         self.backend = backend if backend is not None else HipShardBackend(self.k, local_rank)
         self.dry = bool(getattr(self.backend, "dry", False))
         self.trace: list | None = [] if self.dry else None     # dry runs: (kind, peer, sent, received) per posted transfer
@@ -674,6 +693,52 @@ class DistributedEngine:
         local = self.backend.closed_form_error(kind, self.n, self.rank << self.k, self.l2p)
         return self.max_over_ranks(local)
 
+    # ---- amplitude-level check of states too large to gather ------------------------------
+    def shard_selectors(self) -> list:
+        """(sel_mask, sel_value) per rank: the set of LOGICAL indices rank r holds in the current layout -- the logical
+        qubits that sit on rank bits, with the values r gives them (qsim_fingerprint's filter on a one-GPU state)."""
+        l2p = self.l2p
+        glob = [q for q in range(self.n) if l2p[q] >= self.k]
+        mask = sum(1 << q for q in glob)
+        return [(mask, sum(((r >> (l2p[q] - self.k)) & 1) << q for q in glob)) for r in range(self.world)]
+
+    def fingerprints(self, seed: int = 0) -> list:
+        """Collective: every shard's fingerprint sum_i amp_i w(logical index of i) in its current (staged, moved) layout,
+        gathered on every rank (qsim_fingerprint: evaluated on the device, two doubles per rank cross the links)."""
+        self._flush_local()
+        z = self.backend.fingerprint(self.n, self.rank << self.k, self.l2p, seed)
+        t = self.torch.tensor([z.real, z.imag], dtype=self.torch.float64)
+        if self.dist.get_backend() == "nccl":
+            t = t.cuda()
+        parts = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t)
+        return [complex(float(p[0]), float(p[1])) for p in parts]
+
+    def _reference_fingerprints(self, cd: dict, selector_sets: list, seed: int) -> list:
+        """Rank 0 only: the circuit on ONE device (the whole 2^n state next to the shard: n = 33 is 128 GiB of the 288),
+        gate semantics and order of ref_dense.simulate (ref_dense.py:44-57) through the fused single-GPU path, then the
+        fingerprint of every selector's index set.  Tests with a CPU backend replace this hook."""
+        from quantum_simulations_amd.runner.engine import SingleGpuEngine
+        if hasattr(self.backend, "release_buffers"):
+            self.backend.release_buffers()
+        one = SingleGpuEngine(self.n, device=self.backend.device, mode=self.mode)
+        try:
+            one.init_zero_state()
+            one.execute(one.plan(cd))
+            return [[one.state.fingerprint(self.n, 0, None, seed, m, v) for m, v in sel] for sel in selector_sets]
+        finally:
+            one.close()
+
+    def check_against_single_device(self, cd: dict, runs: list, seed: int = 20260504) -> list:
+        """Collective.  runs = [(fingerprints, selectors), ...] taken after executions of `cd` on the partition (one per
+        layout / staging variant); returns per run max_r |shard fingerprint r - the same index set of a one-device run|.
+        The one-device run happens once, on rank 0; the other ranks wait in the broadcast."""
+        want = [None]
+        if self.rank == 0:
+            want = [self._reference_fingerprints(cd, [sel for _, sel in runs], seed)]
+        self.dist.broadcast_object_list(want, src=0)
+        return [max(abs(g - w) for g, w in zip(got, ref)) for (got, _), ref in zip(runs, want[0])]
+
     # ---- BASELINE configs 4 and 5 on this engine (bench.py at N > 1, tools/run_config.py) ----------------
     def _timed_circuit(self, cd: dict):
         self.init_zero_state()
@@ -687,10 +752,12 @@ class DistributedEngine:
         dt = self.max_over_ranks(time.perf_counter() - t0)
         return dt, len(plan.executions[0])
 
-    def run_baseline_configs(self, gen) -> dict:
+    def run_baseline_configs(self, gen, check_amplitudes: bool = True) -> dict:
         """Config 5: n-qubit GHZ and GHZ+QFT, EVERY amplitude against the closed forms of SURVEY 8c on the
         devices (max-abs-error over all shards, staged layout included).  Config 4: the seeded Clifford+T
-        circuit (depth 60) with and without staging: gate-applications/s, bytes over xGMI, exchange time."""
+        circuit (depth 60) with and without staging: gate-applications/s, bytes over xGMI, exchange time -- and, like
+        the random 1q+CX circuit of the timed region ("checked against a 1-GPU run"), its amplitudes
+        against a one-GPU run of the same circuit through layout-aware per-shard fingerprints."""
         n = self.n
         out = {"config5": [], "config4": None}
         for kind, cd in (("ghz", gen.generate_ghz_circuit(n)), ("ghz_qft", gen.generate_ghz_qft(n))):
@@ -700,16 +767,27 @@ class DistributedEngine:
                                    "seconds": round(dt, 4), "gate_apps_per_s": round(len(cd["gates"]) / dt, 1),
                                    "steps": steps, "max_abs_err_vs_closed_form": err, "pass_1e-10": bool(err < 1e-10),
                                    "norm2": self.norm2(), "xgmi": self.comm_stats()})
-        cd = gen.random_clifford_t_circuit(n, depth=60)
-        rec = {"n_qubits": n, "n_gpus": self.world, "gates": len(cd["gates"]), "local_qubits": self.k}
+        seed = 20260504
         saved = self.staging
-        for label, staging in (("staged", True), ("unstaged", False)):
-            self.staging = staging
-            dt, steps = self._timed_circuit(cd)
-            rec[label] = {"seconds": round(dt, 4), "gate_apps_per_s": round(len(cd["gates"]) / dt, 1), "steps": steps,
-                          "hbm_passes": self.last_passes, "norm2": self.norm2(), "xgmi": self.comm_stats()}
-        self.staging = saved
-        out["config4"] = rec
+        for key, cd, variants in (("config4", gen.random_clifford_t_circuit(n, depth=60), (("staged", True), ("unstaged", False))),
+                                  ("random_1q_cx", gen.random_1q_cx_circuit(n, depth=40), (("staged", True),))):
+            rec = {"n_qubits": n, "n_gpus": self.world, "gates": len(cd["gates"]), "local_qubits": self.k}
+            runs = []
+            for label, staging in variants:
+                self.staging = staging
+                dt, steps = self._timed_circuit(cd)
+                rec[label] = {"seconds": round(dt, 4), "gate_apps_per_s": round(len(cd["gates"]) / dt, 1), "steps": steps,
+                              "hbm_passes": self.last_passes, "norm2": self.norm2(), "xgmi": self.comm_stats()}
+                runs.append((self.fingerprints(seed), self.shard_selectors()))
+            self.staging = saved
+            if check_amplitudes:
+                # EVERY amplitude of the partitioned result enters its shard's fingerprint; the same index sets of a one-GPU
+                # run of the same circuit must give the same sums (north star: "matching reference amplitudes to 1e-10")
+                diffs = self.check_against_single_device(cd, runs, seed)
+                for (label, _), d in zip(variants, diffs):
+                    rec[label]["fingerprint_max_abs_diff_vs_single_gpu"] = d
+                    rec[label]["pass_1e-10"] = bool(d < 1e-10)
+            out[key] = rec
         return out
 
     def comm_stats(self) -> dict:

@@ -94,7 +94,14 @@ def run_world(world: int, rank: int, k: int, emit=print) -> int:
 
 
 def main(world: int, rank: int, k: int) -> int:
+    """bench.py --gpus N --dry-run: rank 0 prints ONE JSON line (all workloads inside)."""
     if world < 2:
-        print(json.dumps({"error": "--dry-run needs --gpus N > 1 under torch.distributed.run (gloo, CPU only)"}))
+        print(json.dumps({"error": "--dry-run needs --gpus N > 1 (gloo, CPU only)"}))
         return 2
-    return run_world(world, rank, k)
+    docs = []
+    rc = run_world(world, rank, k, emit=lambda line: docs.append(json.loads(line)))
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "local_qubits": k, "n_qubits": k + world.bit_length() - 1,
+                          "ok": rc == 0 and all(d["ok"] for d in docs), "exchange": "none (schedule only, gloo control plane)",
+                          "workloads": docs}), flush=True)
+    return rc

@@ -160,7 +160,7 @@ class SingleGpuEngine:
 
 def make_engine(n_qubits: int, world: int = 1, rank: int = 0, local_rank: int = 0,
                 mode: str = "fused", **kw):
-    if world == 1:
+    if world == 1:                      # (rehearsal / exchange only mean something with more than one rank)
         return SingleGpuEngine(n_qubits, device=local_rank, mode=mode)
     from quantum_simulations_amd.runner.distributed import DistributedEngine
     return DistributedEngine(n_qubits, world, rank, local_rank, mode=mode, **kw)

@@ -9,6 +9,41 @@ import torch
 from oracle import dense_oracle as orc
 
 
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _fp_mix(x: np.ndarray) -> np.ndarray:
+    """one splitmix64 round on uint64 arrays (csrc/misc_kernels.h fp_mix)"""
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return x ^ (x >> np.uint64(31))
+
+
+def fingerprint_weights(y: np.ndarray, seed: int) -> np.ndarray:
+    """w(y) of qsim_fingerprint (include/qsim_hip.h) for an array of logical indices."""
+    a = _fp_mix(y.astype(np.uint64) ^ _fp_mix(np.array([seed], dtype=np.uint64))[0])
+    b = _fp_mix(a)
+    wr = (a >> np.uint64(11)).astype(np.float64) * 2.0 ** -52 - 1.0
+    wi = (b >> np.uint64(11)).astype(np.float64) * 2.0 ** -52 - 1.0
+    return wr + 1j * wi
+
+
+def fingerprint_np(amps: np.ndarray, n_total: int, base_index: int = 0, log_to_phys=None, seed: int = 0,
+                   sel_mask: int = 0, sel_value: int = 0) -> complex:
+    """numpy restatement of qsim_fingerprint: the checker of the HIP reduction and the CPU test double's own."""
+    x = base_index + np.arange(amps.size, dtype=np.int64)
+    if log_to_phys is None:
+        y = x
+    else:
+        y = np.zeros_like(x)
+        for q, p in enumerate(log_to_phys):
+            y |= ((x >> p) & 1) << q
+    keep = (y & sel_mask) == sel_value
+    return complex(np.sum(amps[keep] * fingerprint_weights(y[keep], seed)))
+
+
 class CpuShardBackend:
     def __init__(self, k: int):
         self.k = k
@@ -88,6 +123,9 @@ class CpuShardBackend:
         else:
             want = orc.ghz_qft_closed_form(n_total, y)
         return float(np.max(np.abs(self._c("state") - want)))
+
+    def fingerprint(self, n_total, base_index, log_to_phys, seed, sel_mask=0, sel_value=0) -> complex:
+        return fingerprint_np(self._c("state"), n_total, base_index, log_to_phys, seed, sel_mask, sel_value)
 
     def close(self) -> None:
         self._t.clear()

@@ -56,5 +56,8 @@ def test_probe_environment_is_refused(monkeypatch):
         bench.refuse_probe_environment()
     assert e.value.code == 2
     monkeypatch.delenv("QSIM_PLAN_LOOKAHEAD")
-    monkeypatch.setenv("QSIM_DIST_BACKEND", "gloo")
-    bench.refuse_probe_environment()                    # the rehearsal switch is allowed
+    monkeypatch.setenv("QSIM_DIST_BACKEND", "gloo")     # round 3's rehearsal switch: now an explicit flag (--rehearsal),
+    with pytest.raises(SystemExit):                     # no environment variable changes what a bench line means
+        bench.refuse_probe_environment()
+    monkeypatch.delenv("QSIM_DIST_BACKEND")
+    bench.refuse_probe_environment()

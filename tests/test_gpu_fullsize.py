@@ -198,6 +198,26 @@ def _worker(rank, world, port, errors, results):
                     print(f"[staging={staging}] {bad.size} wrong amplitudes, first {bad[:8].tolist()}, last {int(bad[-1])}, "
                           f"AND {int(np.bitwise_and.reduce(bad)):#x} OR {int(np.bitwise_or.reduce(bad)):#x}", file=sys.stderr, flush=True)
                 results.put((staging, fuse, err, norm2, stats["exchanges"], stats["bytes_sent_per_rank"], eng.last_passes))
+            if fuse:
+                # the amplitude check that needs no gather: per-shard fingerprints in the staged /
+                # moved layout against the same index sets of a ONE-device run of the circuit (the product hook: a
+                # 26-qubit SingleGpuEngine on rank 0's device), then the same after two slabs traded places
+                got_fp, sel = eng.fingerprints(5), eng.shard_selectors()
+                (diff,) = eng.check_against_single_device(cd, [(got_fp, sel)], seed=5)
+                assert diff < 1e-10, (staging, diff)
+                if rank == 0:       # ... and against the C oracle's state through the numpy restatement of the weights
+                    from tests.cpu_shard_backend import fingerprint_np
+                    for r, (m, v) in enumerate(sel):
+                        assert abs(fingerprint_np(want, N4, 0, None, 5, m, v) - got_fp[r]) < 1e-10, (staging, r)
+                t = eng.backend.tensor("state")
+                half = t.numel() // 2
+                lo = t[:half].clone()
+                t[:half].copy_(t[half:])
+                t[half:].copy_(lo)
+                del lo
+                assert abs(eng.norm2() - 1.0) < 1e-10                                # the norm does not see it
+                (bad_fp,) = eng.check_against_single_device(cd, [(eng.fingerprints(5), sel)], seed=5)
+                assert bad_fp > 1e-4, bad_fp
             del got
             eng.backend.close()
         eng.close()

@@ -5,8 +5,7 @@
       --master-port 29533 tools/run_config.py --config 5            # 33-qubit GHZ, then GHZ+QFT
   ... --nproc-per-node 4 tools/run_config.py --config 4             # 32-qubit Clifford+T depth 60
 
-  --qubits N scales the run down (e.g. rehearsal: QSIM_DIST_BACKEND=gloo with ranks sharing one
-  GPU).  Config 5 checks EVERY amplitude against the closed forms of SURVEY 8c on the devices
+  --qubits N scales the run down; --rehearsal lets the ranks share one GPU (host-staged gloo exchange).  Config 5 checks EVERY amplitude against the closed forms of SURVEY 8c on the devices
   (max-abs-error reduction over all shards, staged layout included) at 1e-10; config 4 checks
   the norm and compares staged vs unstaged execution on a sampled set of amplitudes.
 Rank 0 prints one JSON line per sub-run.
@@ -41,11 +40,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, choices=[4, 5], required=True)
     ap.add_argument("--qubits", type=int, default=0)
+    ap.add_argument("--rehearsal", action="store_true")
     args = ap.parse_args()
     world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n = args.qubits or (33 if args.config == 5 else 32)
-    eng = DistributedEngine(n, world, rank, local_rank)
+    eng = DistributedEngine(n, world, rank, local_rank, rehearsal=args.rehearsal)
     out = []
     if args.config == 5:
         for kind, cd in (("ghz", gen.generate_ghz_circuit(n)), ("ghz_qft", gen.generate_ghz_qft(n))):
