@@ -104,9 +104,22 @@ typedef struct {
   const qsim_chunk* src; int32_t src_m; int32_t src_bits[3];
   qsim_chunk* dst; int32_t dst_m; int32_t dst_bits[3];
   qsim_chunk* dst_own; int32_t own_pattern;
+  int32_t dst_parts;   /* 0: the slabs are stored by this call.  P = 2, 4, 8 (split form, dst != NULL): this call launches
+                        * everything but the storing of the slabs, which is cut into up to P PIECES -- piece j = the same
+                        * sub-range(s) of every slab (the highest index bits that are neither slab bits nor tile bits of the
+                        * storing pass have the value j; runs keep >= 2^20 amplitudes, so small shards get fewer pieces) --
+                        * and the caller stores them with qsim_apply_ops_io_part(c, j), in any order, posting the exchange
+                        * of piece j (all peers at once: every link busy) while the later pieces are still computed.  The
+                        * storing pass runs as one partial launch per piece, or as qsim_pack_all pieces when it cannot be
+                        * fused.  (-P: the same without the 2^20 floor: tests.) */
 } qsim_ops_io;
 int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits,
                       const double* mats, const qsim_ops_io* io, int* n_passes);
+/* Pieces of the pending split call: piece j of EVERY slab d is the n_runs runs [d * 2^(k - m) + run_offsets[j * n_runs + r],
+ * + run_amps) of the send / receive buffers (a tile bit above the piece bits cuts a piece into two runs). */
+int qsim_apply_ops_io_parts(const qsim_chunk* c, int32_t* n_parts, int32_t* n_runs, uint64_t* run_amps,
+                            uint64_t* run_offsets, int capacity);
+int qsim_apply_ops_io_part(qsim_chunk* c, int part);
 /* The host planner of the fused passes WITHOUT a device (used by the CPU tests): plans the op list
  * for a 2^n_local_qubits chunk and writes one QSIM_PASS_IMAGE_BYTES pass image per planned pass to `out`
  * (layout = the kernel-argument block of k_tile, csrc/tile_kernel.h: record count, tile size T, tile high
@@ -172,6 +185,12 @@ int qsim_comm_world(const qsim_comm* comm);
 /* (send and recv must be chunks on the SAME stream: the transfer is ordered on it) */
 int qsim_comm_exchange(qsim_comm* comm, int n_peers, const int32_t* peers, const qsim_chunk* send,
                        const uint64_t* send_off, qsim_chunk* recv, const uint64_t* recv_off, uint64_t count_amps);
+/* Background form of qsim_comm_exchange: the group runs on the communicator's own transfer stream, behind everything
+ * queued on the chunks' stream so far and BESIDE what is queued on it later (the next piece of a fused re-layout being
+ * computed); qsim_comm_join makes a chunk's stream wait for every background transfer posted so far. */
+int qsim_comm_exchange_bg(qsim_comm* comm, int n_peers, const int32_t* peers, const qsim_chunk* send,
+                          const uint64_t* send_off, qsim_chunk* recv, const uint64_t* recv_off, uint64_t count_amps);
+int qsim_comm_join(qsim_comm* comm, qsim_chunk* c);
 /* qsim_swap_global_local ACROSS GPUs: local qubit local_bits[i] of this rank's shard trades places
  * with rank bit global_bits[i] (qubit k + global_bits[i]) for i < m <= 3 -- the merged all-to-all form
  * of a staging SWAP list (staging.py:136-152).  Every rank of the communicator calls it with the same
@@ -206,6 +225,31 @@ int qsim_apply_2q_pair_qa_local_remote(qsim_comm* comm, qsim_chunk* shard, qsim_
                                        int my_side, int qa, const double U[32]);
 int qsim_apply_2q_pair_qb_local_remote(qsim_comm* comm, qsim_chunk* shard, qsim_chunk* buf, int partner_rank,
                                        int my_side, int qb, const double U[32]);
+
+/* cpu_nonlocal.apply_2q_quad (cpu_nonlocal.py:61-67; the chunk groups of four of single_node.py:315-321) with the four
+ * chunks on four ranks: ranks[j] holds chunk j = 2 bit(qa) + bit(qb) (argument order c00, c01, c10, c11), this rank is
+ * ranks[my_index]; all taking-part ranks call with the same ranks[] and U.  Each rank works on a quarter (a half, when the
+ * matrix touches only two chunks) of the local index range for the whole group: 3/4 of a shard crosses the links each way
+ * and back instead of three shards in; a chunk the matrix leaves alone takes no part and moves nothing.  `buf`: scratch
+ * of the shard's size.  ranks = {r, r, r, r} (r = this rank) is the one-GPU loopback form: the gate then acts on the
+ * shard's own quarters (local qubits k - 1, k - 2).  A host that may change the qubit layout uses the re-layout (m = 2)
+ * and a local gate instead: 3/4 of a shard once, nothing back. */
+int qsim_apply_2q_quad_remote(qsim_comm* comm, qsim_chunk* shard, qsim_chunk* buf, const int32_t ranks[4], int my_index,
+                              const double U[32]);
+/* The fused re-layout as one call (what runner/distributed.py does with qsim_apply_ops_io and its own exchange):
+ *     shard := after( re-layout( before(shard) ) )
+ * The last fused pass of `before` stores the slabs piece by piece (qsim_ops_io::dst_parts, up to n_pieces = 1, 2, 4, 8) into
+ * `send` (own slab into `recv`); the exchange of piece j with all 2^m - 1 peers (one RCCL group: every link busy) runs on
+ * the communicator's transfer stream as soon as piece j is stored, while piece j + 1 is computed; the first pass of `after`
+ * reads the received slabs from `recv` and leaves the state in `shard` in index order.  Two HBM passes fewer than
+ * qsim_comm_relayout between two op lists.  before / after may be NULL or empty (then a pack / unpack pass is made).
+ * as_world != 0: the schedule of rank as_rank in a world of as_world with every transfer looped back to this rank
+ * (runnable on ONE GPU: the result is after(before(shard)) exactly).  Same arguments on every rank of the communicator;
+ * the SWAP-list semantics are those of qsim_swap_global_local (staging.py:136-152). */
+typedef struct { int32_t n_ops; const int32_t* nq; const int32_t* qubits; const double* mats; } qsim_op_list;
+int qsim_comm_relayout_fused(qsim_comm* comm, qsim_chunk* shard, qsim_chunk* send, qsim_chunk* recv,
+                             const qsim_op_list* before, const qsim_op_list* after, int m, const int32_t* local_bits,
+                             const int32_t* global_bits, int n_pieces, int as_rank, int as_world, int* n_passes);
 
 /* ---- synchronisation, reductions, timing ------------------------------------------- */
 /* ---- sparse view (the v3 worker's rows; v3_hisvsim_spark parallel_gate_applicator.py:372-374, state_manager.py:95-106) ---

@@ -59,6 +59,8 @@ SIGNATURES = {
     "qsim_plan_ops": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, C.c_uint64, _P]),
     "qsim_last_pass_count": (C.c_int, [_P]),
     "qsim_apply_ops_io": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.POINTER(C.c_int)]),
+    "qsim_apply_ops_io_part": (C.c_int, [_P, C.c_int]),
+    "qsim_apply_ops_io_parts": (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
     "qsim_apply_1q_pair": (C.c_int, [_P, _P, _P]),
     "qsim_apply_2q_pair_qa_local": (C.c_int, [_P, _P, C.c_int, _P]),
     "qsim_apply_2q_pair_qb_local": (C.c_int, [_P, _P, C.c_int, _P]),
@@ -76,12 +78,16 @@ SIGNATURES = {
     "qsim_comm_rank": (C.c_int, [_P]),
     "qsim_comm_world": (C.c_int, [_P]),
     "qsim_comm_exchange": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_uint64]),
+    "qsim_comm_exchange_bg": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_uint64]),
+    "qsim_comm_join": (C.c_int, [_P, _P]),
     "qsim_comm_relayout": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int]),
     "qsim_comm_relayout_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
     "qsim_comm_relayout_loopback": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int]),
     "qsim_apply_1q_pair_remote": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "qsim_apply_2q_pair_qa_local_remote": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "qsim_apply_2q_pair_qb_local_remote": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "qsim_apply_2q_quad_remote": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
+    "qsim_comm_relayout_fused": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "qsim_count_nonzero": (C.c_int, [_P, C.c_double, C.POINTER(C.c_uint64)]),
     "qsim_export_nonzero": (C.c_int, [_P, C.c_double, C.c_uint64, _P, _P, C.POINTER(C.c_uint64)]),
     "qsim_sync": (C.c_int, [_P]),
@@ -102,7 +108,12 @@ class OpsIo(C.Structure):
     """qsim_ops_io (include/qsim_hip.h): buffers a re-layout is fused with at the ends of an op list."""
     _fields_ = [("src", C.c_void_p), ("src_m", C.c_int32), ("src_bits", C.c_int32 * 3),
                 ("dst", C.c_void_p), ("dst_m", C.c_int32), ("dst_bits", C.c_int32 * 3),
-                ("dst_own", C.c_void_p), ("own_pattern", C.c_int32)]
+                ("dst_own", C.c_void_p), ("own_pattern", C.c_int32), ("dst_parts", C.c_int32)]
+
+
+class OpList(C.Structure):
+    """qsim_op_list (include/qsim_hip.h)"""
+    _fields_ = [("n_ops", C.c_int32), ("nq", C.c_void_p), ("qubits", C.c_void_p), ("mats", C.c_void_p)]
 
 
 class ProfileEntry(C.Structure):

@@ -93,10 +93,16 @@ static int check_comm(const qsim_comm* c, const char* what) {
 static int comm_exchange(qsim_comm* cm, int n_peers, const int32_t* peers, const double2* send, const uint64_t* send_off,
                          double2* recv, const uint64_t* recv_off, uint64_t count, hipStream_t stream) {
   RCCL_TRY(g_rccl.GroupStart());
-  for (int i = 0; i < n_peers; ++i) {
-    RCCL_TRY(g_rccl.Send(send + send_off[i], 2 * count, ncclDouble, peers[i], cm->comm, stream));
-    RCCL_TRY(g_rccl.Recv(recv + recv_off[i], 2 * count, ncclDouble, peers[i], cm->comm, stream));
+  // (an error inside the group must not leave it open: every later RCCL call of the process would queue into it)
+  ncclResult_t bad = ncclSuccess;
+  const char* what = "";
+  for (int i = 0; i < n_peers && bad == ncclSuccess; ++i) {
+    bad = g_rccl.Send(send + send_off[i], 2 * count, ncclDouble, peers[i], cm->comm, stream);
+    what = "ncclSend";
+    if (bad == ncclSuccess) { bad = g_rccl.Recv(recv + recv_off[i], 2 * count, ncclDouble, peers[i], cm->comm, stream); what = "ncclRecv"; }
   }
-  RCCL_TRY(g_rccl.GroupEnd());
+  const ncclResult_t end = g_rccl.GroupEnd();
+  if (bad != ncclSuccess) return fail(QSIM_ERR_HIP, "%s failed: %s", what, g_rccl.GetErrorString(bad));
+  if (end != ncclSuccess) return fail(QSIM_ERR_HIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(end));
   return QSIM_OK;
 }

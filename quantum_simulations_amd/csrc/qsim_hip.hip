@@ -127,6 +127,7 @@ int qsim_destroy(qsim_chunk* c) {
   (void)hipSetDevice(c->device);
   if (c->have_events) { (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); }
   if (c->scratch) (void)hipFree(c->scratch);
+  delete c->pending;
   if (c->owns_memory && c->amp) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->amp);
@@ -626,6 +627,10 @@ int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t
     fio.out.m = io->dst_m;
     for (int i = 0; i < io->dst_m; ++i) fio.out.bits[i] = io->dst_bits[i];
   }
+  const bool parts = io->dst && io->dst_parts != 0;
+  if (c->pending && c->pending->mode != PendingLast::kNone)
+    return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: slab launches of an earlier split call are pending on this chunk (qsim_apply_ops_io_part)");
+  fio.parts = parts;
   int passes = 0;
   if (io->src && !fio.src) {           // not fusable: one unpack pass brings the state into the chunk
     if ((rc = slabs_all(c, io->src_m, io->src_bits, const_cast<qsim_chunk*>(io->src), -1, 0, 1, false, "qsim_apply_ops_io"))) return rc;
@@ -640,7 +645,23 @@ int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t
     if ((rc = qsim_apply_ops_unfused(c, n_ops, nq, qubits, mats))) return rc;
     passes += n_ops;
   }
-  if (io->dst && !fio.fused_out) {     // not fused: pack passes
+  if (parts) {
+    // split form: the slabs are stored piece by piece by qsim_apply_ops_io_part -- partial launches of the planned last
+    // pass, or (nothing fusable) qsim_pack_all pieces of the final state, or nothing (stored already: one part)
+    PendingLast* p = c->pending ? c->pending : (c->pending = new PendingLast());
+    const bool stashed = p->mode == PendingLast::kStashed;
+    p->mode = stashed ? PendingLast::kTile : (fio.fused_out ? PendingLast::kDone : PendingLast::kPack);
+    p->m = io->dst_m;
+    for (int i = 0; i < io->dst_m; ++i) p->bits[i] = io->dst_bits[i];
+    p->dst = io->dst; p->dst_own = io->dst_own; p->own_pattern = io->own_pattern;
+    p->launched = 0;
+    const int min_run_bits = io->dst_parts < 0 ? 3 : 20;        // (negative: tests cut small shards too)
+    const int want = io->dst_parts < 0 ? -io->dst_parts : io->dst_parts;
+    if (p->mode == PendingLast::kTile) plan_parts(p, c->k, want, p->a.h, p->T - kTileLow, min_run_bits);
+    else if (p->mode == PendingLast::kPack) plan_parts(p, c->k, want, nullptr, 0, min_run_bits);
+    else plan_parts(p, c->k, 1, nullptr, 0);
+    if (p->mode == PendingLast::kPack) ++passes;
+  } else if (io->dst && !fio.fused_out) {     // not fused: pack passes
     if ((rc = slabs_all(c, io->dst_m, io->dst_bits, io->dst, io->own_pattern, 0, 1, true, "qsim_apply_ops_io"))) return rc;
     ++passes;
     if (io->own_pattern >= 0) {
@@ -650,6 +671,59 @@ int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t
   }
   c->last_passes = passes;
   if (n_passes) *n_passes = passes;
+  return QSIM_OK;
+}
+
+// Split form of the slab-storing end of qsim_apply_ops_io (qsim_ops_io::dst_parts): store piece `part` of every slab.
+int qsim_apply_ops_io_part(qsim_chunk* c, int part) {
+  int rc = check_chunk(c, "qsim_apply_ops_io_part");
+  if (rc) return rc;
+  PendingLast* p = c->pending;
+  if (!p || p->mode == PendingLast::kNone) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_part: no split op list is pending on this chunk");
+  if (part < 0 || part >= p->n_parts) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_part: part %d out of range", part);
+  if ((p->launched >> part) & 1) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_part: part %d has been stored already", part);
+  HIP_TRY(hipSetDevice(c->device));
+  if (p->mode == PendingLast::kTile) {
+    TileArgs a = p->a;
+    a.nfix = (uint8_t)p->nfix;
+    a.fix_or = 0;
+    for (int i = 0; i < p->nfix; ++i) {
+      int below = 0;
+      for (int j = 0; j < p->T - kTileLow; ++j) below += a.h[j] < p->fix[i];
+      a.fix_pos[i] = (uint8_t)(p->fix[i] - below);
+      if ((part >> i) & 1) a.fix_or |= 1ull << p->fix[i];
+    }
+    if ((rc = launch_tile_any(a, p->T, c, c->stream, p->alg_bytes / (double)p->n_parts))) return rc;
+  } else if (p->mode == PendingLast::kPack) {
+    // (the pieces of qsim_pack_all are the values of the top non-slab index bits: the same cut as plan_parts without a tile)
+    if ((rc = slabs_all(c, p->m, p->bits, p->dst, p->own_pattern, part, p->n_parts, true, "qsim_apply_ops_io_part"))) return rc;
+    if (p->own_pattern >= 0) {
+      // the own slab goes to the receive buffer: its piece as a plain copy of the packed form is not available (skipped
+      // above), so the per-pattern pack writes it; once, with the first part
+      if (p->launched == 0) {
+        const uint64_t slab = 1ull << (c->k - p->m);
+        if ((rc = qsim_pack_bits(c, p->m, p->bits, p->own_pattern, p->dst_own, (uint64_t)p->own_pattern * slab))) return rc;
+      }
+    }
+  }
+  p->launched |= 1u << part;
+  if (p->launched == (p->n_parts >= 32 ? ~0u : (1u << p->n_parts) - 1u)) p->mode = PendingLast::kNone;
+  return QSIM_OK;
+}
+
+// The pieces of the pending split op list: piece j of EVERY slab is the runs [run_offsets[j * n_runs + r], + run_amps),
+// r < n_runs, of the slab (amplitudes, relative to the slab's start d * 2^(k - m) in the send / receive buffers).
+int qsim_apply_ops_io_parts(const qsim_chunk* c, int32_t* n_parts, int32_t* n_runs, uint64_t* run_amps, uint64_t* run_offsets,
+                            int capacity) {
+  if (!c || !c->pending || c->pending->mode == PendingLast::kNone) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_parts: no split op list is pending on this chunk");
+  const PendingLast* p = c->pending;
+  if (n_parts) *n_parts = p->n_parts;
+  if (n_runs) *n_runs = p->n_runs;
+  if (run_amps) *run_amps = p->run_amps;
+  if (run_offsets) {
+    if (capacity < p->n_parts * p->n_runs) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_parts: %d offsets do not fit", p->n_parts * p->n_runs);
+    for (int i = 0; i < p->n_parts * p->n_runs; ++i) run_offsets[i] = p->run_off[(size_t)i];
+  }
   return QSIM_OK;
 }
 
@@ -711,6 +785,39 @@ int qsim_comm_exchange(qsim_comm* cm, int n_peers, const int32_t* peers, const q
   }
   HIP_TRY(hipSetDevice(cm->device));
   return comm_exchange(cm, n_peers, peers, send->amp, send_off, recv->amp, recv_off, count_amps, send->stream);
+}
+
+// Background form: the group is queued on the communicator's transfer stream behind everything queued on the chunks'
+// stream SO FAR; what is queued on the chunks' stream later runs beside it.  qsim_comm_join makes a chunk's stream wait
+// for every background transfer posted so far (the piece pipeline of a fused re-layout: runner/distributed.py).
+int qsim_comm_exchange_bg(qsim_comm* cm, int n_peers, const int32_t* peers, const qsim_chunk* send, const uint64_t* send_off,
+                          qsim_chunk* recv, const uint64_t* recv_off, uint64_t count_amps) {
+  int rc = check_comm(cm, "qsim_comm_exchange_bg");
+  if (rc || (rc = check_chunk(send, "qsim_comm_exchange_bg")) || (rc = check_chunk(recv, "qsim_comm_exchange_bg"))) return rc;
+  if (n_peers < 0 || (n_peers && (!peers || !send_off || !recv_off))) return fail(QSIM_ERR_INVALID, "qsim_comm_exchange_bg: bad peer list");
+  if (send->amp == recv->amp) return fail(QSIM_ERR_INVALID, "qsim_comm_exchange_bg: send and receive chunks must differ");
+  if (send->stream != recv->stream) return fail(QSIM_ERR_INVALID, "qsim_comm_exchange_bg: the send and the receive chunk must share a stream");
+  for (int i = 0; i < n_peers; ++i) {
+    if (peers[i] < 0 || peers[i] >= cm->world) return fail(QSIM_ERR_INVALID, "qsim_comm_exchange_bg: peer %d out of range", peers[i]);
+    if (send_off[i] > amps(send) || count_amps > amps(send) - send_off[i] || recv_off[i] > amps(recv) || count_amps > amps(recv) - recv_off[i])
+      return fail(QSIM_ERR_INVALID, "qsim_comm_exchange_bg: slice %d outside its chunk", i);
+  }
+  HIP_TRY(hipSetDevice(cm->device));
+  if (!cm->xfer_stream) HIP_TRY(hipStreamCreateWithFlags(&cm->xfer_stream, hipStreamNonBlocking));
+  for (auto& e : cm->ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(cm->ev[14], send->stream));
+  HIP_TRY(hipStreamWaitEvent(cm->xfer_stream, cm->ev[14], 0));
+  return comm_exchange(cm, n_peers, peers, send->amp, send_off, recv->amp, recv_off, count_amps, cm->xfer_stream);
+}
+
+int qsim_comm_join(qsim_comm* cm, qsim_chunk* c) {
+  int rc = check_comm(cm, "qsim_comm_join");
+  if (rc || (rc = check_chunk(c, "qsim_comm_join"))) return rc;
+  if (!cm->xfer_stream) return QSIM_OK;                     // nothing was ever posted in the background
+  HIP_TRY(hipSetDevice(cm->device));
+  HIP_TRY(hipEventRecord(cm->ev[15], cm->xfer_stream));
+  HIP_TRY(hipStreamWaitEvent(c->stream, cm->ev[15], 0));
+  return QSIM_OK;
 }
 
 // ---- all-to-all re-layout: ONE schedule, computed by a pure function --------------------------------------------
@@ -826,6 +933,179 @@ int qsim_comm_relayout_loopback(qsim_comm* cm, qsim_chunk* state, qsim_chunk* bu
   RelayoutPlan p;
   if ((rc = relayout_plan(as_rank, as_world, state->k, m, local_bits, global_bits, n_pieces, &p))) return rc;
   return relayout_run(cm, state, buf0, buf1, m, local_bits, p, true);
+}
+
+// The fused re-layout as ONE call for a host without the Python runner (what runner/distributed.py does with
+// qsim_apply_ops_io + its own exchange): shard := after( re-layout( before(shard) ) ).  The last fused pass of `before`
+// stores the slabs piece by piece (qsim_ops_io::dst_parts) on the chunk's stream; the exchange of piece j -- every peer in
+// one RCCL group, all links busy -- runs on the communicator's transfer stream as soon as piece j is stored, while piece
+// j + 1 is computed; the first pass of `after` reads the received slabs from `recv`.  Two HBM passes fewer than
+// qsim_comm_relayout between two op lists, and the compute of all pieces but the first hidden behind the links.
+int qsim_comm_relayout_fused(qsim_comm* cm, qsim_chunk* shard, qsim_chunk* send, qsim_chunk* recv,
+                             const qsim_op_list* before, const qsim_op_list* after, int m, const int32_t* local_bits,
+                             const int32_t* global_bits, int n_pieces, int as_rank, int as_world, int* n_passes) {
+  int rc = check_comm(cm, "qsim_comm_relayout_fused");
+  if (rc || (rc = check_chunk(shard, "qsim_comm_relayout_fused")) || (rc = check_chunk(send, "qsim_comm_relayout_fused")) ||
+      (rc = check_chunk(recv, "qsim_comm_relayout_fused"))) return rc;
+  if (send->stream != shard->stream || recv->stream != shard->stream)
+    return fail(QSIM_ERR_INVALID, "qsim_comm_relayout_fused: the shard and both buffers must share a stream");
+  const bool loopback = as_world != 0;
+  RelayoutPlan p;
+  if ((rc = relayout_plan(loopback ? as_rank : cm->rank, loopback ? as_world : cm->world, shard->k, m, local_bits, global_bits, 1, &p))) return rc;
+  static const qsim_op_list none = {0, nullptr, nullptr, nullptr};
+  if (!before) before = &none;
+  if (!after) after = &none;
+  if (n_pieces != 1 && n_pieces != 2 && n_pieces != 4 && n_pieces != 8 && n_pieces != -2 && n_pieces != -4 && n_pieces != -8)
+    return fail(QSIM_ERR_INVALID, "qsim_comm_relayout_fused: n_pieces must be 1, 2, 4 or 8");
+  HIP_TRY(hipSetDevice(cm->device));
+  if (!cm->xfer_stream) HIP_TRY(hipStreamCreateWithFlags(&cm->xfer_stream, hipStreamNonBlocking));
+  for (auto& e : cm->ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  qsim_ops_io io;
+  std::memset(&io, 0, sizeof io);
+  io.dst = send; io.dst_m = m; io.dst_own = recv; io.own_pattern = p.own;
+  for (int i = 0; i < m; ++i) io.dst_bits[i] = local_bits[i];
+  io.dst_parts = n_pieces == 1 ? -1 : n_pieces;            // (always the split form: -1 = one piece)
+  int passes_before = 0, passes_after = 0;
+  if ((rc = qsim_apply_ops_io(shard, before->n_ops, before->nq, before->qubits, before->mats, &io, &passes_before))) return rc;
+  int32_t n_parts = 0, n_runs = 0;
+  uint64_t run_amps = 0, run_off[64];
+  if ((rc = qsim_apply_ops_io_parts(shard, &n_parts, &n_runs, &run_amps, run_off, 64))) return rc;
+  if (p.n_peers * n_runs > 64) return fail(QSIM_ERR_INVALID, "internal: %d transfers in one piece", p.n_peers * n_runs);
+  for (int j = 0; j < n_parts; ++j) {
+    if ((rc = qsim_apply_ops_io_part(shard, j))) return rc;
+    HIP_TRY(hipEventRecord(cm->ev[j], shard->stream));
+    HIP_TRY(hipStreamWaitEvent(cm->xfer_stream, cm->ev[j], 0));
+    int32_t peers[64];
+    uint64_t offs[64];
+    int n = 0;
+    for (int i = 0; i < p.n_peers; ++i)
+      for (int r = 0; r < n_runs; ++r) {
+        peers[n] = loopback ? cm->rank : p.peers[i];
+        offs[n++] = p.offs[i] + run_off[j * n_runs + r];
+      }
+    if ((rc = comm_exchange(cm, n, peers, send->amp, offs, recv->amp, offs, run_amps, cm->xfer_stream))) return rc;
+  }
+  HIP_TRY(hipEventRecord(cm->ev[15], cm->xfer_stream));
+  HIP_TRY(hipStreamWaitEvent(shard->stream, cm->ev[15], 0));
+  std::memset(&io, 0, sizeof io);
+  io.src = recv; io.src_m = m; io.own_pattern = -1;
+  for (int i = 0; i < m; ++i) io.src_bits[i] = local_bits[i];
+  if ((rc = qsim_apply_ops_io(shard, after->n_ops, after->nq, after->qubits, after->mats, &io, &passes_after))) return rc;
+  if (n_passes) *n_passes = passes_before + passes_after;
+  return QSIM_OK;
+}
+
+// cpu_nonlocal.apply_2q_quad (cpu_nonlocal.py:61-67; chunk groups of four, single_node.py:315-321) with the four chunks
+// on four ranks: ranks[j] holds chunk j = 2 bit(qa) + bit(qb) (the argument order c00, c01, c10, c11) and this rank is
+// ranks[my_index].  The local index range is cut into four quarters and every taking-part rank WORKS ON some of them: it
+// receives those quarters of its partners' shards into `buf`, applies the matrix across the copies and its own quarter,
+// and sends the results back -- 3/4 of a shard each way, twice, instead of three whole shards in.  A chunk the matrix
+// leaves alone (its row and column are the identity's: the |0x> chunks of a gate controlled by qa) takes no part: its
+// rank returns at once, nobody sends to it or waits for it (two active chunks: a 2x2 across the pair, half a shard each
+// way).  ranks = {r, r, r, r} with r = this rank is the one-GPU loopback form: every transfer comes back, so the gate
+// acts on the shard's own four quarters (chunk j = quarter j: local qubits k - 1 and k - 2).
+int qsim_apply_2q_quad_remote(qsim_comm* cm, qsim_chunk* shard, qsim_chunk* buf, const int32_t ranks[4], int my_index, const double U[32]) {
+  const char* what = "qsim_apply_2q_quad_remote";
+  int rc = check_comm(cm, what);
+  if (rc || (rc = check_chunk(shard, what)) || (rc = check_chunk(buf, what))) return rc;
+  if (!ranks || !U) return fail(QSIM_ERR_INVALID, "%s: null argument", what);
+  if (buf->k != shard->k || buf->amp == shard->amp || buf->stream != shard->stream)
+    return fail(QSIM_ERR_INVALID, "%s: the buffer must be a distinct chunk of the shard's size on the shard's stream", what);
+  if (shard->k < 2) return fail(QSIM_ERR_INVALID, "%s: shards of at least 4 amplitudes are needed", what);
+  if (my_index < 0 || my_index > 3) return fail(QSIM_ERR_INVALID, "%s: my_index must be 0..3", what);
+  bool loopback = true;
+  for (int j = 0; j < 4; ++j) {
+    if (ranks[j] < 0 || ranks[j] >= cm->world) return fail(QSIM_ERR_INVALID, "%s: rank %d out of range", what, ranks[j]);
+    loopback = loopback && ranks[j] == cm->rank;
+  }
+  if (!loopback) {
+    if (ranks[my_index] != cm->rank) return fail(QSIM_ERR_INVALID, "%s: ranks[my_index] must be this rank", what);
+    for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < j; ++i)
+        if (ranks[i] == ranks[j]) return fail(QSIM_ERR_INVALID, "%s: the four chunks live on four different ranks (or all on this one: loopback)", what);
+  }
+  // chunks the matrix touches (a unitary touches none, or at least two; exactly three: treated as all four)
+  int act[4], n_act = 0;
+  bool active[4];
+  for (int j = 0; j < 4; ++j) {
+    bool unit = true;
+    for (int c = 0; c < 4; ++c) {
+      const double want = c == j ? 1.0 : 0.0;
+      unit = unit && U[2 * (4 * j + c)] == want && U[2 * (4 * j + c) + 1] == 0.0 && U[2 * (4 * c + j)] == want && U[2 * (4 * c + j) + 1] == 0.0;
+    }
+    active[j] = !unit;
+  }
+  for (int j = 0; j < 4; ++j) n_act += active[j];
+  if (n_act == 0) return QSIM_OK;
+  if (n_act == 3) { n_act = 4; for (bool& a : active) a = true; }
+  if (!active[my_index]) return QSIM_OK;
+  if (n_act == 1) {                                        // a phase on one chunk (CZ, CR with both qubits global): no exchange
+    const double f[8] = {U[2 * (5 * my_index)], U[2 * (5 * my_index) + 1], 0, 0, 0, 0, U[2 * (5 * my_index)], U[2 * (5 * my_index) + 1]};
+    return qsim_apply_1q(shard, 0, f);
+  }
+  for (int j = 0, i = 0; j < 4; ++j) if (active[j]) act[i++] = j;
+  HIP_TRY(hipSetDevice(cm->device));
+  const u64 Q = amps(shard) >> 2;
+  auto owner = [&](int q) { return act[q % n_act]; };      // the chunk whose rank works on quarter q
+  auto slot_of = [&](int q, int j) -> u64 {                 // where partner chunk j's quarter q sits in MY buffer (I work on q)
+    u64 s = 0;
+    for (int qq = 0; qq < 4; ++qq) {
+      if (owner(qq) != my_index) continue;
+      for (int i = 0; i < n_act; ++i) {
+        if (act[i] == my_index) continue;
+        if (qq == q && act[i] == j) return s;
+        ++s;
+      }
+    }
+    return 0;                                               // (unreachable)
+  };
+  // One RCCL group per direction.  Between two ranks the k-th send meets the k-th receive: both sides walk the quarters in
+  // ascending order (and, inside a quarter, the partners in ascending chunk order).
+  auto exchange = [&](bool back) -> int {
+    RCCL_TRY(g_rccl.GroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (int q = 0; q < 4 && bad == ncclSuccess; ++q) {
+      const int o = owner(q);
+      if (o == my_index) {                                  // partners' copies of quarter q: in (there) / out (back)
+        for (int i = 0; i < n_act && bad == ncclSuccess; ++i) {
+          if (act[i] == my_index) continue;
+          double2* copy = buf->amp + slot_of(q, act[i]) * Q;
+          bad = back ? g_rccl.Send(copy, 2 * Q, ncclDouble, ranks[act[i]], cm->comm, shard->stream)
+                     : g_rccl.Recv(copy, 2 * Q, ncclDouble, ranks[act[i]], cm->comm, shard->stream);
+        }
+      } else {                                              // my quarter q: out to the rank that works on it / back in
+        double2* mine = shard->amp + (u64)q * Q;
+        bad = back ? g_rccl.Recv(mine, 2 * Q, ncclDouble, ranks[o], cm->comm, shard->stream)
+                   : g_rccl.Send(mine, 2 * Q, ncclDouble, ranks[o], cm->comm, shard->stream);
+      }
+    }
+    const ncclResult_t end = g_rccl.GroupEnd();             // (closed on every path)
+    if (bad != ncclSuccess) return fail(QSIM_ERR_HIP, "%s: RCCL send / receive failed: %s", what, g_rccl.GetErrorString(bad));
+    if (end != ncclSuccess) return fail(QSIM_ERR_HIP, "%s: ncclGroupEnd failed: %s", what, g_rccl.GetErrorString(end));
+    return QSIM_OK;
+  };
+  if ((rc = exchange(false))) return rc;
+  for (int q = 0; q < 4; ++q) {
+    if (owner(q) != my_index) continue;
+    qsim_chunk view[4];
+    for (int j = 0; j < 4; ++j) {
+      view[j] = *shard;                                     // device, stream, cache policy of the shard's allocation
+      view[j].k = shard->k - 2;
+      view[j].owns_memory = false; view[j].scratch = nullptr; view[j].have_events = false; view[j].pending = nullptr;
+      view[j].amp = j == my_index ? shard->amp + (u64)q * Q : (active[j] ? buf->amp + slot_of(q, j) * Q : nullptr);
+    }
+    if (n_act == 4) {
+      Group g = {{&view[0], &view[1], &view[2], &view[3]}, 4, shard->k - 2};
+      if ((rc = gate_2q(g, shard->k - 1, shard->k - 2, U, shard->stream))) return rc;
+    } else {                                                // two active chunks a < b: the 2x2 [[U_aa, U_ab], [U_ba, U_bb]] across the pair
+      const int a = act[0], b = act[1];
+      const double W[8] = {U[2 * (4 * a + a)], U[2 * (4 * a + a) + 1], U[2 * (4 * a + b)], U[2 * (4 * a + b) + 1],
+                           U[2 * (4 * b + a)], U[2 * (4 * b + a) + 1], U[2 * (4 * b + b)], U[2 * (4 * b + b) + 1]};
+      Group g = {{&view[a], &view[b], nullptr, nullptr}, 2, shard->k - 2};
+      if ((rc = gate_1q(g, shard->k - 2, W, shard->stream))) return rc;
+    }
+  }
+  return exchange(true);
 }
 
 // The reference's partner-chunk butterflies with the partner chunk on ANOTHER rank: both ranks call with each

@@ -125,12 +125,25 @@ struct TileArgs {
   TileSlab slab_in, slab_out;   // where the tile with logical base b starts in amp / amp_out (kTilePermIn / kTilePermOut)
   uint8_t nbits;           // k: index bits of the chunk
   uint8_t perm;            // kTilePermIn | kTilePermOut | kTileOwnOut
-  uint8_t reserved[22];
+  // ---- a launch over PART of the tiles (round 4; nfix = 0: all tiles) ---------------------------------------------
+  // The slab-storing pass of a fused re-layout is launched once per destination slab, so that the exchange of slab d can
+  // be posted while the launches of the other slabs still run: the tiles of ONE launch are those whose logical base has
+  // the nfix index bits of the slab pattern fixed (fix_or = their values in place); the tile number then enumerates the
+  // remaining non-tile bits.  fix_pos[j] (ascending) = position of the j-th fixed bit MINUS the number of tile high bits
+  // below it: the zeros of the fixed bits are inserted first, into the number that still lacks the tile bits.
+  uint8_t nfix;
+  uint8_t fix_pos[3];
+  uint8_t reserved0[2];
+  u64 fix_or;
+  uint8_t reserved[8];
   uint32_t stream[kTileStreamBytes / 4];
 };
 constexpr uint8_t kTilePermIn = 1, kTilePermOut = 2, kTileOwnOut = 4;
 constexpr uint8_t kTileDirectIn = 0x10, kTileDirectOut = 0x20, kTileOrderMask = 0x03;
 static_assert(sizeof(TileArgs) == kTileArgBytes, "kernel arguments are one 4 KiB block");
+static_assert(offsetof(TileArgs, nbits) % 8 == 0 && offsetof(TileArgs, nfix) == offsetof(TileArgs, nbits) + 2 &&
+              offsetof(TileArgs, fix_pos) == offsetof(TileArgs, nbits) + 3 && offsetof(TileArgs, fix_or) == offsetof(TileArgs, nbits) + 8,
+              "k_tile<PART> reads {nbits .. fix_pos} and fix_or as two aligned 8-byte words");
 static_assert(offsetof(TileArgs, stream) == kTileStreamOff, "record offsets are relative to the argument block");
 
 // XOR-swizzled LDS slot (measured: within 1 % of five other swizzles and of none -- bank
@@ -165,7 +178,10 @@ constexpr int tile_waves(int T, int tiles_per_wg = 1) {
 // always true for states of up to 31 qubits): every access is `global_* v, voffset, s[base]` with a scalar
 // 64-bit base per element row -- no 64-bit vector arithmetic (the r01 form spent ~35 quarter-rate
 // v_lshl_add_u64 / v_lshlrev_b64 per wave and pass on addresses).
-template <int T, bool NT, bool WIDE, int TPW>
+// PART = true: a launch over the tiles of ONE destination slab (TileArgs::nfix; a separate instantiation, so the
+// all-tiles kernel keeps its register allocation: with the fixed-bit code inside it the compiler spilled 56 scalar
+// registers to vector lanes instead of 22).
+template <int T, bool NT, bool WIDE, int TPW, bool PART = false>
 __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const TileArgs a) {
   constexpr int N = 1 << T;
   constexpr int LOW = kTileLow;
@@ -209,6 +225,7 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
   }
   // Which tile a workgroup takes: TPW consecutive tiles per workgroup; order 0 = consecutive tiles in flight,
   // 1 = hashed, 2 = bit-reversed (probe build only, see tile_order_for).  ntiles is a power of two.
+  const unsigned nfix = PART ? __builtin_amdgcn_readfirstlane((unsigned)a.nfix) : 0u;   // fixed index bits of a partial launch
   auto tile_base = [&](unsigned i) -> u64 {
     // (consecutive tiles per workgroup, workgroups dealt round-robin over the XCDs; measured against it,
     // profiles/r02z_*: one contiguous eighth of the tiles per XCD +1.1 %, the two tiles half the state apart +4.7 %,
@@ -220,12 +237,27 @@ __global__ __launch_bounds__(kTileThreads, tile_waves(T, TPW)) void k_tile(const
     if ((a.order & kTileOrderMask) == 2) tile = a.ntiles > 1 ? __brev(tile) >> (__clz(a.ntiles) + 1) : 0;
 #endif
     u64 base = (u64)tile << LOW;                      // the tile number enumerates the non-tile bits
+    u64 fix_or = 0;
+    if (PART && nfix) {                               // (uniform; a launch over the tiles of one piece)
+      // two aligned 8-byte scalar loads from the kernel-argument segment: {nbits, perm, nfix, fix_pos[3], -, -} and fix_or
+      // (read where they are used: nothing of them lives across the gate engine; scalar loads ignore the low address
+      // bits, so the fields are never addressed byte-wise)
+      typedef __attribute__((address_space(4))) const u64 cu64_t;
+      cu64_t* fp = (cu64_t*)((__attribute__((address_space(4))) const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TileArgs, nbits));
+      asm volatile("" : "+s"(fp));
+      const u64 w0 = fp[0];
+      fix_or = fp[1];
+      for (unsigned j = 0; j < nfix; ++j) {
+        const int p = (int)((w0 >> (8 * (3 + j))) & 0xffu);
+        base = ((base >> p) << (p + 1)) | (base & ((1ull << p) - 1));
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
       const int p = hs[j];
       base = ((base >> p) << (p + 1)) | (base & ((1ull << p) - 1));
     }
-    return base;                                      // LOGICAL index of the tile's first amplitude
+    return base | fix_or;                             // LOGICAL index of the tile's first amplitude
   };
   // Re-laid-out buffers (TileArgs::slab_in / slab_out): the tile's position from its logical base -- wave-uniform
   // scalar work (~25 instructions), only in the passes that carry a layout.  (The pointer is made opaque so that the

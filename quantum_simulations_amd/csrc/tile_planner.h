@@ -113,7 +113,8 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   if constexpr (T > kTileBitsMax || T < kTileThreadBits) {
     return fail(QSIM_ERR_INVALID, "internal: tile size %d not built", T);
   } else {
-  const u64 ntiles = 1ull << (c->k - T);
+  if (a.nfix && (T != kTileBitsMax || a.nfix > 3 || c->k - T < a.nfix)) return fail(QSIM_ERR_INVALID, "internal: partial launch of a %d-bit tile", T);
+  const u64 ntiles = 1ull << (c->k - T - a.nfix);       // (a.nfix: the tiles of one destination slab of a fused re-layout)
   if (ntiles > 0xFFFFFFFFull) return fail(QSIM_ERR_INVALID, "internal: too many tiles");
   TileArgs args = a;
   args.ntiles = (uint32_t)ntiles;
@@ -151,12 +152,32 @@ static int launch_tile(const TileArgs& a, const qsim_chunk* c, hipStream_t strea
   for (int i = 0; i < kTileThreadBits - kTileLow && i < T - kTileLow; ++i) wide = wide || args.lay_in[i] >= 28 || args.lay_out[i] >= 28;
   bool nt = c->span_bytes > tuning().mall_bytes;       // cache policy by state size (gate_plan.h)
   if (tuning().force_nt >= 0) nt = tuning().force_nt != 0;
-  ProfileScope prof(6, alg_bytes, stream, nt, 32.0 * (double)amps(c));
+  ProfileScope prof(6, alg_bytes, stream, nt, 32.0 * (double)(ntiles << T));
   // Two tiles per workgroup, the second one's loads in flight while the first is computed on
   // (profiles/r02r_ab_prefetch_before_engine.txt: -3.9 % per pass; 4 or 8 tiles per workgroup lose it again,
   // profiles/r02z_ab_paired_stores.txt).  Also for the 64-bit-offset form (110 VGPRs: the 32 KiB of LDS admit four
   // workgroups per CU, so 128 are there); not for small grids.
   constexpr int TPW = QSIM_TILES_PER_WG;
+  if constexpr (T == kTileBitsMax) {
+    if (args.nfix) {                                       // one destination slab: the PART instantiations (full tiles only)
+      const bool two = TPW > 1 && ntiles >= (u64)TPW * 4096;
+      const unsigned grid = (unsigned)(two ? ntiles / TPW : ntiles);
+      if (two) {
+        if (nt && wide) hipLaunchKernelGGL((k_tile<T, true, true, TPW, true>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+        else if (nt) hipLaunchKernelGGL((k_tile<T, true, false, TPW, true>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+        else if (wide) hipLaunchKernelGGL((k_tile<T, false, true, TPW, true>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+        else hipLaunchKernelGGL((k_tile<T, false, false, TPW, true>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+      } else {
+        if (nt && wide) hipLaunchKernelGGL((k_tile<T, true, true, 1, true>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+        else if (nt) hipLaunchKernelGGL((k_tile<T, true, false, 1, true>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+        else if (wide) hipLaunchKernelGGL((k_tile<T, false, true, 1, true>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+        else hipLaunchKernelGGL((k_tile<T, false, false, 1, true>), dim3(grid), dim3(kTileThreads), 0, stream, args);
+      }
+      prof.done(stream);
+      HIP_TRY(hipGetLastError());
+      return QSIM_OK;
+    }
+  }
   if (TPW > 1 && ntiles >= (u64)TPW * 4096) {
     const unsigned grid = (unsigned)(ntiles / TPW);
     if (nt && wide) hipLaunchKernelGGL((k_tile<T, true, true, TPW>), dim3(grid), dim3(kTileThreads), 0, stream, args);
@@ -1088,8 +1109,72 @@ struct FusedIo {
   SlabLayout out;
   qsim_chunk* dst_own = nullptr;     // ... except slab `own_pattern`, which goes to this one (same layout)
   int own_pattern = -1;
+  bool parts = false;                // the slab-storing pass is not launched here: it is left pending in the chunk and
+                                     // launched slab by slab (qsim_apply_ops_io_part), so each slab's exchange can start early
   bool fused_in = false, fused_out = false;   // results
 };
+
+// The slab-storing pass of an op list whose caller asked for the split form (qsim_ops_io::dst_parts): planned, not yet
+// launched.  It is stored PIECE by piece: piece j = the amplitudes whose `nfix` fixed index bits (the highest index bits
+// that are neither slab bits nor tile bits of the pass) have the value j -- the same sub-range(s) of EVERY slab, so the
+// exchange of piece j uses all links at once while the pieces behind it are still being computed.  kTile: one partial
+// launch of the pass per piece; kPack (nothing fusable: the state is final in the chunk): one qsim_pack_all piece;
+// kDone: the pass could not be split and has stored everything already (one part, nothing to launch).
+struct PendingLast {
+  enum Mode { kNone = 0, kStashed, kTile, kPack, kDone };   // kStashed: launch_planned has put the pass here, the caller's slab description is still missing
+  int mode = kNone;
+  TileArgs a;
+  int T = 0;
+  double alg_bytes = 0;
+  int m = 0;
+  int32_t bits[3] = {0, 0, 0};
+  qsim_chunk* dst = nullptr;
+  qsim_chunk* dst_own = nullptr;
+  int own_pattern = -1;
+  int n_parts = 1;                   // 2^nfix
+  int nfix = 0;
+  int fix[3] = {0, 0, 0};            // the fixed index bits, ascending (piece j: bit i of j <-> fix[i])
+  int n_runs = 1;                    // contiguous runs of one piece inside a slab (tile bits above the lowest fixed bit split it)
+  u64 run_amps = 0;
+  std::vector<u64> run_off;          // [part * n_runs + r]: offset of the run inside every slab, in amplitudes
+  unsigned launched = 0;             // bit j: piece j has been stored
+};
+
+// Which pieces the slab-storing pass is cut into: up to `want` (2, 4, 8) pieces over the highest index bits that are
+// neither slab bits nor (tile != nullptr) high bits of the pass, as long as a run keeps >= 2^min_run_bits amplitudes and
+// a piece has at most 8 runs per slab.
+static void plan_parts(PendingLast* p, int k, int want, const uint8_t* tile_high, int n_tile_high, int min_run_bits = 20) {
+  auto is_slab = [&](int b) { for (int i = 0; i < p->m; ++i) if (p->bits[i] == b) return true; return false; };
+  auto is_tile = [&](int b) { for (int j = 0; j < n_tile_high; ++j) if (tile_high[j] == b) return true; return false; };
+  auto sigma = [&](int b) { int s = b; for (int i = 0; i < p->m; ++i) s -= p->bits[i] < b; return s; };   // position in the slab offset
+  int want_bits = 0;
+  while ((2 << want_bits) <= want && want_bits < 3) ++want_bits;
+  p->nfix = 0; p->n_parts = 1; p->n_runs = 1; p->run_amps = 1ull << (k - p->m); p->run_off.assign(1, 0);
+  for (int nb = want_bits; nb >= 1; --nb) {
+    int fix[3], found = 0, above_tile = 0;
+    for (int b = k - 1; b >= kTileLow && found < nb; --b) {
+      if (is_slab(b)) continue;
+      if (is_tile(b)) { ++above_tile; continue; }
+      fix[found++] = b;
+    }
+    if (found < nb) continue;
+    const int fmin = fix[nb - 1];
+    if (sigma(fmin) < min_run_bits || above_tile > 3) continue;
+    p->nfix = nb; p->n_parts = 1 << nb; p->n_runs = 1 << above_tile; p->run_amps = 1ull << sigma(fmin);
+    for (int i = 0; i < nb; ++i) p->fix[i] = fix[nb - 1 - i];          // ascending
+    std::vector<int> tb;                                                  // tile bits above fmin, ascending
+    for (int b = fmin + 1; b < k; ++b) if (!is_slab(b) && is_tile(b)) tb.push_back(b);
+    p->run_off.assign((size_t)p->n_parts * p->n_runs, 0);
+    for (int j = 0; j < p->n_parts; ++j)
+      for (int r = 0; r < p->n_runs; ++r) {
+        u64 off = 0;
+        for (int i = 0; i < nb; ++i) if ((j >> i) & 1) off |= 1ull << sigma(p->fix[i]);
+        for (size_t t = 0; t < tb.size(); ++t) if ((r >> t) & 1) off |= 1ull << sigma(tb[t]);
+        p->run_off[(size_t)j * p->n_runs + r] = off;
+      }
+    return;
+  }
+}
 
 // One planned pass on its way to the device: buffers, the re-layout of the op list's ends, launch.
 static int launch_planned(qsim_chunk* c, TileArgs& a, int T, double alg_bytes, bool first, bool last, FusedIo* io) {
@@ -1123,6 +1208,11 @@ static int launch_planned(qsim_chunk* c, TileArgs& a, int T, double alg_bytes, b
       }
       io->fused_out = true;
     }
+  }
+  if (io && last && io->dst && io->parts && io->fused_out && T == kTileBitsMax) {
+    PendingLast* p = c->pending ? c->pending : (c->pending = new PendingLast());
+    p->mode = PendingLast::kStashed; p->a = a; p->T = T; p->alg_bytes = alg_bytes; p->launched = 0;
+    return QSIM_OK;                  // (qsim_apply_ops_io fills in the slab description and keeps it pending)
   }
   if (tuning().debug_stats < 2) return launch_tile_any(a, T, c, c->stream, alg_bytes);
   // QSIM_DEBUG_STATS=2: time every pass synchronously and print its shape (profiling aid)

@@ -157,11 +157,13 @@ class DeviceChunk:
         return lib.qsim_last_pass_count(self._h) if fused else len(ops)
 
     # ---- sync / reductions / timing -------------------------------------------------
-    def apply_ops_io(self, ops, src=None, dst=None) -> int:
+    def apply_ops_io(self, ops, src=None, dst=None, parts: int = 0) -> int:
         """`apply_ops` with a re-layout fused into its ends (qsim_apply_ops_io): `src` = (chunk, bits): the state
         is read from that chunk in the slab layout of `pack_all` over `bits`; `dst` = (chunk, bits, own_chunk,
         own_pattern): it is left in `chunk` in slab layout, slab `own_pattern` (>= 0) in `own_chunk`.  Returns the
-        HBM passes made."""
+        HBM passes made.  `parts` = 2, 4, 8 (with `dst`): split form -- the slabs are NOT stored by this call but piece
+        by piece by `store_part(j)` for every j < len(`pending_parts()`), so that each piece's exchange can be posted
+        while the later pieces are still computed (negative: no 2^20-amplitude floor on a run, for tests)."""
         nq, qs, mats = pack_ops(ops) if not (isinstance(ops, tuple) and len(ops) == 3 and isinstance(ops[0], np.ndarray)) else ops
         io = _lib.OpsIo()
         keep = []
@@ -180,10 +182,23 @@ class DeviceChunk:
             if own_chunk is not None and own_pattern >= 0:
                 io.dst_own, io.own_pattern = own_chunk._h, int(own_pattern)
             keep += [chunk, own_chunk]
+        io.dst_parts = int(parts) if dst is not None else 0
         passes = C.c_int()
         _lib.check(_lib.load().qsim_apply_ops_io(self._h, len(nq), nq.ctypes.data_as(C.c_void_p), qs.ctypes.data_as(C.c_void_p),
                                                  mats.ctypes.data_as(C.c_void_p), C.byref(io), C.byref(passes)))
         return passes.value
+
+    def pending_parts(self) -> list:
+        """Pieces of the pending split `apply_ops_io`: [[(offset, amplitudes), ...runs], ...pieces] -- piece j of EVERY
+        slab d is those runs of [d * slab, (d + 1) * slab) in the send / receive buffers (qsim_apply_ops_io_parts)."""
+        n_parts, n_runs, run = C.c_int32(), C.c_int32(), C.c_uint64()
+        offs = np.zeros(64, dtype=np.uint64)
+        _lib.check(_lib.load().qsim_apply_ops_io_parts(self._h, C.byref(n_parts), C.byref(n_runs), C.byref(run),
+                                                       offs.ctypes.data_as(C.c_void_p), 64))
+        return [[(int(offs[j * n_runs.value + r]), int(run.value)) for r in range(n_runs.value)] for j in range(n_parts.value)]
+
+    def store_part(self, part: int) -> None:
+        _lib.check(_lib.load().qsim_apply_ops_io_part(self._h, int(part)))
 
     def sync(self) -> None:
         _lib.check(_lib.load().qsim_sync(self._h))
@@ -336,6 +351,17 @@ class Comm:
                                                   so.ctypes.data_as(C.c_void_p), recv._h,
                                                   ro.ctypes.data_as(C.c_void_p), int(count)))
 
+    def exchange_bg(self, peers, send: DeviceChunk, send_off, recv: DeviceChunk, recv_off, count: int) -> None:
+        """qsim_comm_exchange_bg: the group on the communicator's transfer stream, beside later work on the chunks' stream."""
+        p = np.asarray(peers, dtype=np.int32)
+        so, ro = np.asarray(send_off, dtype=np.uint64), np.asarray(recv_off, dtype=np.uint64)
+        _lib.check(_lib.load().qsim_comm_exchange_bg(self._h, len(p), p.ctypes.data_as(C.c_void_p), send._h,
+                                                     so.ctypes.data_as(C.c_void_p), recv._h,
+                                                     ro.ctypes.data_as(C.c_void_p), int(count)))
+
+    def join(self, chunk: DeviceChunk) -> None:
+        _lib.check(_lib.load().qsim_comm_join(self._h, chunk._h))
+
     def relayout(self, state: DeviceChunk, buf0: DeviceChunk, buf1: DeviceChunk, local_bits, global_bits,
                  n_pieces: int = 4) -> None:
         lb, gb = np.asarray(local_bits, dtype=np.int32), np.asarray(global_bits, dtype=np.int32)
@@ -351,6 +377,33 @@ class Comm:
         _lib.check(_lib.load().qsim_comm_relayout_loopback(self._h, state._h, buf0._h, buf1._h, len(lb),
                                                            lb.ctypes.data_as(C.c_void_p), gb.ctypes.data_as(C.c_void_p),
                                                            int(n_pieces), int(as_rank), int(as_world)))
+
+    def relayout_fused(self, shard: DeviceChunk, send: DeviceChunk, recv: DeviceChunk, before, after, local_bits,
+                       global_bits, n_pieces: int = 4, as_rank: int = 0, as_world: int = 0) -> int:
+        """qsim_comm_relayout_fused: shard := after(re-layout(before(shard))) with the slabs stored piece by piece by the
+        last pass of `before`, exchanged while the next piece is computed, and loaded by the first pass of `after`.
+        `before` / `after`: [(qubits, U)] (may be empty).  as_world != 0: loopback form on one GPU.  Returns HBM passes."""
+        lb, gb = np.asarray(local_bits, dtype=np.int32), np.asarray(global_bits, dtype=np.int32)
+        keep, lists = [], []
+        for ops in (before, after):
+            ol = _lib.OpList()
+            if ops:
+                nq, qs, mats = pack_ops(ops)
+                keep.append((nq, qs, mats))
+                ol.n_ops, ol.nq, ol.qubits, ol.mats = len(nq), nq.ctypes.data, qs.ctypes.data, mats.ctypes.data
+            lists.append(ol)
+        passes = C.c_int()
+        _lib.check(_lib.load().qsim_comm_relayout_fused(self._h, shard._h, send._h, recv._h, C.byref(lists[0]), C.byref(lists[1]),
+                                                        len(lb), lb.ctypes.data_as(C.c_void_p), gb.ctypes.data_as(C.c_void_p),
+                                                        int(n_pieces), int(as_rank), int(as_world), C.byref(passes)))
+        return passes.value
+
+    def apply_2q_quad_remote(self, shard: DeviceChunk, buf: DeviceChunk, ranks, my_index: int, U) -> None:
+        """cpu_nonlocal.apply_2q_quad with the four chunks on the ranks `ranks` (chunk j = 2 bit(qa) + bit(qb)); this
+        rank holds chunk `my_index`.  ranks = [r] * 4 with r = this rank: one-GPU loopback form."""
+        m, p = _mat_ptr(U, 4)
+        r = np.asarray(ranks, dtype=np.int32)
+        _lib.check(_lib.load().qsim_apply_2q_quad_remote(self._h, shard._h, buf._h, r.ctypes.data_as(C.c_void_p), int(my_index), p))
 
     def apply_1q_pair_remote(self, shard: DeviceChunk, buf: DeviceChunk, partner: int, my_side: int, U) -> None:
         m, p = _mat_ptr(U, 2)

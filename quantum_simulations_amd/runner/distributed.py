@@ -99,15 +99,40 @@ class HipShardBackend:
         self.torch.cuda.synchronize(self.device)
 
     # ---- arithmetic -----------------------------------------------------------------
-    def apply_ops(self, ops, src=None, dst=None) -> int:
+    def apply_ops(self, ops, src=None, dst=None, parts: int = 0) -> int:
         """HBM passes made.  src = (buffer, bits): the shard is read from that buffer in slab layout; dst = (buffer,
         bits, own_buffer, own_pattern): it is left there in slab layout (qsim_apply_ops_io: the re-layout's pack /
-        unpack ride in the last / first fused pass)."""
+        unpack ride in the last / first fused pass).  parts (with dst): split form -- the slabs are stored piece by piece
+        by `store_part(j)` for every piece of `pending_parts()`."""
         st = self.chunk("state")
         if src is None and dst is None:
             return st.apply_ops(ops)
         return st.apply_ops_io(ops, src=(self.chunk(src[0]), src[1]) if src else None,
-                               dst=(self.chunk(dst[0]), dst[1], self.chunk(dst[2]), dst[3]) if dst else None)
+                               dst=(self.chunk(dst[0]), dst[1], self.chunk(dst[2]), dst[3]) if dst else None, parts=parts)
+
+    def pending_parts(self) -> list:
+        return self.chunk("state").pending_parts()
+
+    def store_part(self, j: int) -> None:
+        self.chunk("state").store_part(j)
+
+    # ---- exchange through the library's own communicator (DistributedEngine(exchange="cabi")) -----------------
+    def comm_init(self, dist, rank: int, world: int) -> None:
+        """qsim_comm over RCCL: rank 0 makes the unique id, the existing process group hands the 128 bytes around."""
+        from quantum_simulations_amd.kernel.device import Comm
+        box = [Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        self.comm = Comm(self.device, rank, world, box[0])
+
+    def exchange_bg(self, send: str, recv: str, entries) -> None:
+        """entries [(peer, offset_amps, count_amps)] (one count): one RCCL group on the communicator's transfer stream,
+        behind everything queued on the shard's stream so far; later work on that stream does not wait for it."""
+        peers = [e[0] for e in entries]
+        offs = [e[1] for e in entries]
+        self.comm.exchange_bg(peers, self.chunk(send), offs, self.chunk(recv), offs, entries[0][2])
+
+    def exchange_join(self) -> None:
+        self.comm.join(self.chunk("state"))
 
     def pack_all(self, bits, dst: str, skip_pattern: int, piece: int = 0, n_pieces: int = 1) -> None:
         self.chunk("state").pack_all(bits, self.chunk(dst), skip_pattern, piece, n_pieces)
@@ -138,6 +163,9 @@ class HipShardBackend:
 
     def close(self) -> None:
         self.sync()
+        if getattr(self, "comm", None) is not None:
+            self.comm.close()
+            self.comm = None
         for c in self._chunks.values():
             c.close()
         self._chunks.clear()
@@ -192,12 +220,24 @@ class DryBackend:
     def sync(self) -> None:
         pass
 
-    def apply_ops(self, ops, src=None, dst=None) -> int:
+    def apply_ops(self, ops, src=None, dst=None, parts: int = 0) -> int:
         for side in (src, dst):
             if side is not None:
                 self._check(side[1], 0, 1)
         self.local_passes += 1
+        if dst is not None and parts:
+            # the pieces the library would cut the slab-storing pass into: up to `parts`, each run >= 2^20 amplitudes
+            slab = 1 << (self.k - len(dst[1]))
+            n = max(1, min(parts, slab >> 20))
+            self._parts = [[(j * (slab // n), slab // n)] for j in range(n)]
         return 1
+
+    def pending_parts(self) -> list:
+        return self._parts
+
+    def store_part(self, j: int) -> None:
+        if not 0 <= j < len(self._parts):
+            raise ValueError("bad part")
 
     def pack_all(self, bits, dst, skip_pattern, piece=0, n_pieces=1) -> None:
         self._check(bits, piece, n_pieces)
@@ -224,8 +264,8 @@ class DistributedEngine:
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
-        if world & (world - 1) or world < 2:
-            raise ValueError("world size must be a power of two >= 2")
+        if world & (world - 1) or world < 1:
+            raise ValueError("world size must be a power of two")      # (1: no global qubit, nothing is ever exchanged: plumbing tests)
         self.n, self.world, self.rank = n_qubits, world, rank
         self.p = world.bit_length() - 1
         self.k = n_qubits - self.p
@@ -254,8 +294,15 @@ class DistributedEngine:
         self.exchange_api = exchange
         self.exchange = "gloo-rehearsal" if rehearsal else ("rccl" if backend is None else f"gloo ({type(backend).__name__})")
         self.backend = backend if backend is not None else HipShardBackend(self.k, local_rank)
+        if exchange == "cabi":
+            # the transfers are posted by the library's own RCCL communicator (qsim_comm_exchange_bg on its transfer
+            # stream) instead of torch.distributed P2P: the same schedule, the path a C-only host uses
+            if rehearsal or not hasattr(self.backend, "comm_init"):
+                raise ValueError("exchange='cabi' needs one rank per GPU and the HIP backend (RCCL inside libqsim_hip.so)")
+            self.backend.comm_init(dist, rank, world)
         self.dry = bool(getattr(self.backend, "dry", False))
         self.trace: list | None = [] if self.dry else None     # dry runs: (kind, peer, sent, received) per posted transfer
+        self.trace_posts = 0                                   # dry runs: groups posted (>= 2 per fused re-layout: pieces)
         self.l2p_planned = list(range(n_qubits))   # logical qubit -> physical index bit as the PLANS see it
         self._dyn = list(range(n_qubits))          # planned physical bit -> actual physical bit (swap-and-stay moves)
         self._flat: list = []                      # qubit lists of the running execution, in order (victim choice)
@@ -285,33 +332,45 @@ class DistributedEngine:
     def _rank_bit(self, phys_qubit: int) -> int:
         return (self.rank >> (phys_qubit - self.k)) & 1
 
-    def _post(self, transfers):
-        """Post [(peer, send_tensor, recv_tensor)] together, without waiting (RCCL: the transfer is
-        ordered after everything already queued on the current stream)."""
+    def _post(self, send: str, recv: str, entries):
+        """Post entries [(peer, start, count)] together -- `count` float64 elements at offset `start` of buffer `send` go
+        to `peer`, as many arrive from it at the same place of `recv` -- without waiting (RCCL: the group is ordered after
+        everything already queued on the shard's stream and runs beside what is queued later).  One group = every peer
+        at once: all links busy."""
         dist, torch = self.dist, self.torch
         if self.dry:
-            for peer, send, recv in transfers:
-                self.trace.append((self._trace_kind, int(peer), send.numel() * send.element_size(),
-                                   recv.numel() * recv.element_size()))
-                self.xgmi_bytes_sent += send.numel() * send.element_size()
+            self.trace_posts += 1
+            for peer, start, count in entries:
+                self.backend.tensor(send)[start:start + count]          # (slice bounds are checked)
+                self.backend.tensor(recv)[start:start + count]
+                self.trace.append((self._trace_kind, int(peer), count * 8, count * 8))
+                self.xgmi_bytes_sent += count * 8
             return ([], [])
+        if not entries:
+            return ([], [])
+        self.xgmi_bytes_sent += sum(c for _, _, c in entries) * 8
+        if self.exchange_api == "cabi":
+            self.backend.exchange_bg(send, recv, [(peer, start // 2, count // 2) for peer, start, count in entries])
+            return ("cabi", [])
+        st, rt = self.backend.tensor(send), self.backend.tensor(recv)
         staged, ops = [], []
         host = dist.get_backend() == "gloo"
-        for peer, send, recv in transfers:
-            if host and send.is_cuda:  # rehearsal of several ranks on one GPU: stage through host
-                s_h, r_h = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
-                staged.append((recv, r_h))
-                send, recv = s_h, r_h
-            ops.append(dist.P2POp(dist.isend, send, peer))
-            ops.append(dist.P2POp(dist.irecv, recv, peer))
-            self.xgmi_bytes_sent += send.numel() * send.element_size()
-        return (dist.batch_isend_irecv(ops) if ops else [], staged)
+        for peer, start, count in entries:
+            s_t, r_t = st[start:start + count], rt[start:start + count]
+            if host and s_t.is_cuda:   # rehearsal of several ranks on one GPU: stage through host
+                s_h, r_h = s_t.cpu(), torch.empty(r_t.shape, dtype=r_t.dtype)
+                staged.append((r_t, r_h))
+                s_t, r_t = s_h, r_h
+            ops.append(dist.P2POp(dist.isend, s_t, peer))
+            ops.append(dist.P2POp(dist.irecv, r_t, peer))
+        return (dist.batch_isend_irecv(ops), staged)
 
-    @staticmethod
-    def _finish(posted) -> None:
-        """Received data may be used by what is queued after this (RCCL: the current stream waits,
-        not the host)."""
+    def _finish(self, posted) -> None:
+        """Received data may be used by what is queued after this (RCCL: the shard's stream waits, not the host)."""
         works, staged = posted
+        if works == "cabi":
+            self.backend.exchange_join()
+            return
         for work in works:
             work.wait()
         for dev_t, host_t in staged:
@@ -342,24 +401,20 @@ class DistributedEngine:
     def _queue_local(self, op) -> None:
         self._pending.append(op)
 
-    def _flush_local(self, dst=None) -> bool:
-        """Run the queued local ops (reading the shard from the receive buffer it may still live in).  With `dst`
-        = (send buffer, local bits, receive buffer, own pattern) the last pass leaves the shard in slab layout for the
-        exchange that follows; returns whether that happened (False: nothing was queued, the caller packs)."""
+    def _flush_local(self) -> None:
+        """Run the queued local ops (reading the shard from the receive buffer it may still live in)."""
         if self._pending:
             ops, self._pending = self._pending, []
-            if self._state_in is None and dst is None:
+            if self._state_in is None:
                 self._passes += self.backend.apply_ops(ops) or 0
             else:
-                self._passes += self.backend.apply_ops(ops, src=self._state_in, dst=dst) or 0
+                self._passes += self.backend.apply_ops(ops, src=self._state_in) or 0
             self._state_in = None
-            return dst is not None
-        if self._state_in is not None:               # nothing to ride on: one unpack pass brings the shard home
+        elif self._state_in is not None:             # nothing to ride on: one unpack pass brings the shard home
             buf, bits = self._state_in
             self.backend.unpack_all(bits, buf, -1)
             self._passes += 1
             self._state_in = None
-        return False
 
     # ---- state ---------------------------------------------------------------------------
     def init_zero_state(self) -> None:
@@ -511,7 +566,7 @@ class DistributedEngine:
         m = len(pairs)
         slab = 2 << (self.k - m)                       # float64 elements per slab
         mine = sum(((self.rank >> (g - self.k)) & 1) << i for i, g in enumerate(glo))
-        send, recv = self.backend.tensor("buf0"), self.backend.tensor("buf1")
+        send = self.backend.tensor("buf0")
         peers = []
         for d in range(1 << m):
             if d == mine:
@@ -523,21 +578,27 @@ class DistributedEngine:
         pieces = self._relayout_pieces(self.k - m)
         part = slab // pieces
         if self.fuse_relayout and min(loc) >= 3 and self.k - m >= 3:
-            # fused: the queued local ops' last pass writes the slabs (own slab straight into the receive buffer), the
-            # next local pass will read them from there.  (A slab bit inside a 128-byte line would break whole-line
-            # accesses: the unfused path below handles it.)  The receive buffer must not be the one the shard
-            # currently lives in (a one-pass op list would read and write it at once): a third buffer takes turns.
+            # Fused: the queued local ops' last pass writes the slabs (own slab straight into the receive buffer), the next
+            # local pass will read them from there.  (A slab bit inside a 128-byte line would break whole-line accesses:
+            # the unfused path below handles it.)  The receive buffer must not be the one the shard currently lives in (a
+            # one-pass op list would read and write it at once): a third buffer takes turns.
+            # What overlaps what: the slab-storing pass is cut into up to `relayout_pieces` PIECES
+            # (the same sub-range(s) of every slab: qsim_ops_io::dst_parts) and the exchange of piece j -- one group
+            # with all 2^m - 1 peers, every link busy -- is posted as soon as piece j is stored, so it travels while the
+            # pieces behind it are computed; only the first piece's compute and the last piece's transfer are exposed on
+            # the send side.  The first pass AFTER the exchange still waits for every piece (its tiles read all slabs).
             rname = "buf2" if (self._state_in is not None and self._state_in[0] == "buf1") else "buf1"
-            recv = self.backend.tensor(rname)
-            if not self._flush_local(dst=("buf0", loc, rname, mine)):
-                self.backend.pack_all(loc, "buf0", -1)
-                self._passes += 1
-                if not self.dry:
-                    recv[mine * slab:(mine + 1) * slab].copy_(send[mine * slab:(mine + 1) * slab])
-            # (whole slabs in ONE group: there is no pack / unpack left to overlap the pieces with, and fewer, larger
-            # messages are what the links like)
+            ops, self._pending = self._pending, []
+            self._passes += self.backend.apply_ops(ops, src=self._state_in, dst=("buf0", loc, rname, mine),
+                                                   parts=self._split_parts(pieces)) or 0
+            self._state_in = None
             timer = self._comm_timer(send)
-            self._finish(self._post([(peer, send[d * slab:(d + 1) * slab], recv[d * slab:(d + 1) * slab]) for d, peer in peers]))
+            posted = []
+            for j, runs in enumerate(self.backend.pending_parts()):
+                self.backend.store_part(j)
+                posted.append(self._post("buf0", rname, [(peer, d * slab + 2 * off, 2 * cnt) for d, peer in peers for off, cnt in runs]))
+            for pst in posted:
+                self._finish(pst)
             self._comm_done(timer)
             self._state_in = (rname, list(loc))
             return
@@ -547,14 +608,21 @@ class DistributedEngine:
         posted = []
         self.backend.pack_all(loc, "buf0", mine, 0, pieces)        # slab d at offset d * 2^(k-m)
         for s in range(pieces):
-            posted.append(self._post([(peer, send[d * slab + s * part:d * slab + (s + 1) * part],
-                                       recv[d * slab + s * part:d * slab + (s + 1) * part]) for d, peer in peers]))
+            posted.append(self._post("buf0", "buf1", [(peer, d * slab + s * part, part) for d, peer in peers]))
             if s + 1 < pieces:
                 self.backend.pack_all(loc, "buf0", mine, s + 1, pieces)
         for s in range(pieces):
             self._finish(posted[s])
             self.backend.unpack_all(loc, "buf1", mine, s, pieces)
         self._comm_done(timer)
+
+    def _split_parts(self, pieces: int) -> int:
+        """qsim_ops_io::dst_parts for a fused re-layout: the configured pieces; negative (no 2^20-amplitude floor on a
+        run) when the engine was built with a lower floor (tests on small shards)."""
+        want = max(pieces, 2) if self.relayout_pieces > 1 else 1
+        if want == 1:
+            return -1                                        # split form with one piece
+        return want if self.min_piece_qubits >= 20 else -want
 
     def _relayout_pieces(self, slab_qubits: int) -> int:
         """Pieces per slab: the configured count, capped so that a piece keeps >= 2^20 amplitudes

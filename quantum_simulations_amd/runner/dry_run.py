@@ -68,7 +68,8 @@ def run_world(world: int, rank: int, k: int, emit=print) -> int:
         dist.all_gather_object(traces, eng.trace)
         stats = [None] * world
         dist.all_gather_object(stats, {"bytes": eng.xgmi_bytes_sent, "exchanges": eng.exchanges,
-                                       "local_batches": eng.backend.local_passes, "layout": eng.l2p})
+                                       "local_batches": eng.backend.local_passes, "layout": eng.l2p,
+                                       "groups_posted": eng.trace_posts})
         if rank == 0:
             problems = check(traces, world, k)
             failed += bool(problems)
@@ -81,7 +82,9 @@ def run_world(world: int, rank: int, k: int, emit=print) -> int:
                 "dry_run": title, "n_qubits": n, "n_gpus": world, "local_qubits": k, "gates": len(cd["gates"]),
                 "executions": repeats, "ok": not problems, "problems": problems[:8],
                 "per_rank": [{"rank": r, "transfers": len(traces[r]), "bytes_sent": stats[r]["bytes"],
-                              "exchanges": stats[r]["exchanges"], "local_batches": stats[r]["local_batches"]}
+                              "exchanges": stats[r]["exchanges"], "local_batches": stats[r]["local_batches"],
+                              # posting points: a fused re-layout posts one group (all peers at once) per piece
+                              "groups_posted": stats[r]["groups_posted"]}
                              for r in range(world)],
                 "rank0_by_kind": {kd: {"transfers": c, "bytes": b} for kd, (c, b) in kinds.items()},
                 "rank0_schedule": [{"kind": kind, "peer": peer, "bytes": s} for kind, peer, s, _ in traces[0][:64]],

@@ -73,7 +73,7 @@ class CpuShardBackend:
     def sync(self) -> None:
         pass
 
-    def apply_ops(self, ops, src=None, dst=None) -> None:
+    def apply_ops(self, ops, src=None, dst=None, parts: int = 0) -> None:
         """src / dst: the fused re-layout ends of qsim_apply_ops_io (runner/distributed.py), restated with the slab
         helpers below: read the shard from a receive buffer in slab layout / leave it in slab layout for the exchange
         (own slab in the receive buffer)."""
@@ -82,11 +82,32 @@ class CpuShardBackend:
         orc.apply_ops(self._c("state"), ops)
         if dst is not None:
             buf, bits, own_buf, own = dst
-            self.pack_all(bits, buf, own)
-            if own >= 0:
-                slab = 1 << (self.k - len(bits))
-                self._c(own_buf)[own * slab:(own + 1) * slab] = self._c("state")[self._slab_index(bits, own)]
+            slab = 1 << (self.k - len(bits))
+            if parts:
+                # split form (qsim_ops_io::dst_parts): nothing is stored yet -- piece j of every slab by store_part(j)
+                n = max(1, min(abs(parts), slab))
+                self._split = (buf, list(bits), own_buf, own, n, self._c("state").copy())
+                self._parts = [[(j * (slab // n), slab // n)] for j in range(n)]
+                self._stored = set()
+            else:
+                self.pack_all(bits, buf, own)
+                if own >= 0:
+                    self._c(own_buf)[own * slab:(own + 1) * slab] = self._c("state")[self._slab_index(bits, own)]
             self._c("state")[:] = np.nan          # unspecified afterwards: nobody may read it before the next src
+
+    def pending_parts(self) -> list:
+        return self._parts
+
+    def store_part(self, j: int) -> None:
+        buf, bits, own_buf, own, n, final = self._split
+        assert 0 <= j < n and j not in self._stored
+        self._stored.add(j)
+        slab = 1 << (self.k - len(bits))
+        part = slab // n
+        for d in range(1 << len(bits)):
+            sel = self._slab_index(bits, d)[j * part:(j + 1) * part]
+            target = own_buf if d == own else buf
+            self._c(target)[d * slab + j * part:d * slab + (j + 1) * part] = final[sel]
 
     def _slab_index(self, bits, pattern: int) -> np.ndarray:
         idx = np.arange(1 << self.k, dtype=np.int64)

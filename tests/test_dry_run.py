@@ -52,6 +52,10 @@ def test_schedule_is_symmetric_at_full_size(world):
         for kind, agg in d["rank0_by_kind"].items():
             assert kind in ("relayout", "swap-and-stay")
             assert 0 < agg["bytes"] <= agg["transfers"] * shard
+        for r in d["per_rank"]:
+            # a re-layout is posted piece by piece -- one group of all its peers per piece, the next piece being computed
+            # meanwhile: at 30 local qubits every re-layout has at least two posting points
+            assert r["groups_posted"] >= 2 * r["exchanges"] > 0 or r["exchanges"] == 0, r
         sent = {r["bytes_sent"] for r in d["per_rank"]}
         assert len(sent) == 1, "every rank ships the same number of bytes"        # (the schedule is symmetric)
     # GHZ needs exactly one re-layout of all global qubits: (1 - 2^-p) of a shard per rank

@@ -99,3 +99,81 @@ def test_relayout_pipeline_loopback_runs_the_piece_loop():
     comm.close()
     for c in (state, b0, b1):
         c.close()
+
+
+def test_quad_remote_loopback_against_the_oracle():
+    """qsim_apply_2q_quad_remote (cpu_nonlocal.py:61-67 with the four chunks on four ranks) in its one-GPU loopback form:
+    every transfer comes back, so chunk j of the group is quarter j of the shard and the result must equal
+    oracle.apply_2q_quad on the four quarters -- whichever chunk this rank plays.  Dense 4x4 (all four chunks take part),
+    a gate controlled by qa (chunks |10>, |11> only: a 2x2 across the pair, the other two ranks return at once), SWAP
+    (chunks |01>, |10>), CZ (a phase on chunk |11> alone: no exchange at all), the identity."""
+    comm = Comm(0, 0, 1, Comm.unique_id())
+    k = 13
+    a = _rand(k, 21)
+    Q = 1 << (k - 2)
+    rng = np.random.default_rng(3)
+    dense = np.linalg.qr(rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4)))[0]
+    cu = np.eye(4, dtype=complex)
+    cu[2:, 2:] = gt.RY(0.9) @ gt.H()
+    cases = {"dense": (dense, [0, 1, 2, 3]), "CNOT(qa,qb)": (gt.CNOT(), [2, 3]), "CU(qa,qb)": (cu, [2, 3]),
+             "SWAP": (gt.SWAP(), [1, 2]), "CZ": (gt.CZ(), [3]), "identity": (np.eye(4, dtype=complex), [])}
+    state, buf = DeviceChunk.from_numpy(a), DeviceChunk.zero_state(k, set_amp0=False)
+    for name, (U, active) in cases.items():
+        want = a.copy()
+        orc.apply_2q_quad(*(want[j * Q:(j + 1) * Q] for j in range(4)), U)
+        for me in range(4):
+            state.upload(a)
+            comm.apply_2q_quad_remote(state, buf, [0, 0, 0, 0], me, U)
+            state.sync()
+            got = state.download()
+            if me in active or name == "dense":
+                np.testing.assert_allclose(got, want, rtol=0, atol=1e-13, err_msg=f"{name} as chunk {me}")
+            else:
+                np.testing.assert_array_equal(got, a, err_msg=f"{name}: chunk {me} takes no part")
+    with pytest.raises(ValueError):
+        comm.apply_2q_quad_remote(state, buf, [0, 0, 0, 1], 0, dense)        # rank out of range
+    with pytest.raises(ValueError):
+        comm.apply_2q_quad_remote(state, state, [0, 0, 0, 0], 0, dense)      # buffer = shard
+    with pytest.raises(ValueError):
+        comm.apply_2q_quad_remote(state, buf, [0, 0, 0, 0], 4, dense)
+    comm.close()
+    state.close()
+    buf.close()
+
+
+@pytest.mark.parametrize("k,pieces", [(13, -4), (16, -2), (23, 4)])
+def test_relayout_fused_loopback_against_the_oracle(k, pieces):
+    """qsim_comm_relayout_fused as rank `as_rank` of a world of 2 / 4 / 8 with every transfer looped back: the slabs this
+    rank "receives" are its own, so the call must equal after(before(state)) of the oracle -- while running the real
+    schedule: split last pass, per-piece RCCL groups on the transfer stream, events, first pass reading the receive
+    buffer.  Pass counts: two fewer than pack + exchange + unpack around the same op lists."""
+    from tests.test_gpu_kernels import _random_ops
+    comm = Comm(0, 0, 1, Comm.unique_id())
+    a = _rand(k, 31 + k)
+    state, send, recv = DeviceChunk.from_numpy(a), DeviceChunk.zero_state(k, set_amp0=False), DeviceChunk.zero_state(k, set_amp0=False)
+    rng = np.random.default_rng(50 + k)
+    for trial, (as_world, as_rank, m) in enumerate(((2, 1, 1), (4, 2, 2), (8, 5, 3), (8, 0, 1), (4, 3, 2))):
+        lb = [int(b) for b in rng.choice(np.arange(3 if trial != 3 else 0, k), size=m, replace=False)]
+        gb = [int(g) for g in rng.permutation(as_world.bit_length() - 1)[:m]]
+        before = _random_ops(k, 40, 100 * k + trial) if trial != 1 else []
+        after = _random_ops(k, 40, 200 * k + trial) if trial != 2 else []
+        want = a.copy()
+        orc.apply_ops(want, before)
+        orc.apply_ops(want, after)
+        state.upload(a)
+        plain = DeviceChunk.from_numpy(a)
+        plain_passes = (plain.apply_ops(before) if before else 0) + (plain.apply_ops(after) if after else 0)
+        plain.close()
+        passes = comm.relayout_fused(state, send, recv, before, after, lb, gb, pieces, as_rank, as_world)
+        state.sync()
+        np.testing.assert_allclose(state.download(), want, rtol=0, atol=1e-11, err_msg=f"k={k} trial={trial} bits {lb}<->{gb}")
+        assert passes <= plain_passes + 2, (trial, passes, plain_passes)
+        if min(lb) >= 3 and before and after and k >= 16:
+            assert passes <= plain_passes + 1, (trial, passes, plain_passes)     # at most one end not fused (slab bit = tile bit)
+    with pytest.raises(ValueError):
+        comm.relayout_fused(state, send, recv, [], [], [3], [3], 4, 0, 8)         # rank bit 3 does not exist in a world of 8
+    with pytest.raises(ValueError):
+        comm.relayout_fused(state, send, recv, [], [], [3], [0], 3, 0, 2)         # n_pieces
+    comm.close()
+    for c in (state, send, recv):
+        c.close()
