@@ -231,8 +231,9 @@ int qsim_apply_2q_pair_qb_local_remote(qsim_comm* comm, qsim_chunk* shard, qsim_
  * ranks[my_index]; all taking-part ranks call with the same ranks[] and U.  Each rank works on a quarter (a half, when the
  * matrix touches only two chunks) of the local index range for the whole group: 3/4 of a shard crosses the links each way
  * and back instead of three shards in; a chunk the matrix leaves alone takes no part and moves nothing.  `buf`: scratch
- * of the shard's size.  ranks = {r, r, r, r} (r = this rank) is the one-GPU loopback form: the gate then acts on the
- * shard's own quarters (local qubits k - 1, k - 2).  A host that may change the qubit layout uses the re-layout (m = 2)
+ * of the shard's size.  ranks = {r, r, r, r} (r = this rank) is the one-GPU loopback form: with four chunks taking part
+ * the gate then acts on the shard's own quarters (chunk j = quarter j: local qubits k - 1, k - 2), with two as their 2x2
+ * on local qubit k - 2, with one as its phase on the whole shard.  A host that may change the qubit layout uses the re-layout (m = 2)
  * and a local gate instead: 3/4 of a shard once, nothing back. */
 int qsim_apply_2q_quad_remote(qsim_comm* comm, qsim_chunk* shard, qsim_chunk* buf, const int32_t ranks[4], int my_index,
                               const double U[32]);

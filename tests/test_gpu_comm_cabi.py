@@ -103,8 +103,8 @@ def test_relayout_pipeline_loopback_runs_the_piece_loop():
 
 def test_quad_remote_loopback_against_the_oracle():
     """qsim_apply_2q_quad_remote (cpu_nonlocal.py:61-67 with the four chunks on four ranks) in its one-GPU loopback form:
-    every transfer comes back, so chunk j of the group is quarter j of the shard and the result must equal
-    oracle.apply_2q_quad on the four quarters -- whichever chunk this rank plays.  Dense 4x4 (all four chunks take part),
+    every transfer comes back, so with all four chunks taking part chunk j of the group is quarter j of the shard and the
+    result must equal oracle.apply_2q_quad on the four quarters -- whichever chunk this rank plays.  Dense 4x4 (all four chunks take part),
     a gate controlled by qa (chunks |10>, |11> only: a 2x2 across the pair, the other two ranks return at once), SWAP
     (chunks |01>, |10>), CZ (a phase on chunk |11> alone: no exchange at all), the identity."""
     comm = Comm(0, 0, 1, Comm.unique_id())
@@ -120,7 +120,14 @@ def test_quad_remote_loopback_against_the_oracle():
     state, buf = DeviceChunk.from_numpy(a), DeviceChunk.zero_state(k, set_amp0=False)
     for name, (U, active) in cases.items():
         want = a.copy()
-        orc.apply_2q_quad(*(want[j * Q:(j + 1) * Q] for j in range(4)), U)
+        if len(active) == 2:
+            # two chunks take part: each works on every second quarter, so looped back the pair (chunk a, chunk b) is
+            # (quarter 0, quarter 1) and (quarter 2, quarter 3): the 2x2 restriction of U on local qubit k - 2
+            orc.apply_1q(want, k - 2, U[np.ix_(active, active)])
+        elif len(active) == 1:
+            want = a * U[active[0], active[0]]                                   # one chunk: its phase, on the shard that holds it
+        else:
+            orc.apply_2q_quad(*(want[j * Q:(j + 1) * Q] for j in range(4)), U)   # chunk j = quarter j
         for me in range(4):
             state.upload(a)
             comm.apply_2q_quad_remote(state, buf, [0, 0, 0, 0], me, U)
