@@ -289,7 +289,8 @@ int qsim_time_end(qsim_chunk* c, float* elapsed_ms);       /* record + synchroni
 
 /* ---- per-launch timing for roofline reports (bench.py) ------------------------------- */
 /* Between begin and end every gate kernel launched on c's stream is bracketed by HIP events
- * (no synchronisation, no extra kernels).  qsim_profile_end synchronises the stream and
+ * (no synchronisation, no extra kernels).  One profile per STREAM: handles on different streams (qsim_wrap) may be
+ * profiled at the same time from different host threads; a second begin on a stream whose profile is open fails.  qsim_profile_end synchronises the stream and
  * returns, per kernel class, the launch count, the summed event time, the summed
  * algorithmic bytes (per gate-application 32 B per amplitude the gate touches,
  * summed over the gates of a launch -- a fused pass counts every gate it applies) and

@@ -111,23 +111,27 @@ struct LaunchRecord {
   bool streaming;     // the non-temporal (Infinity-Cache bypassing) instantiation ran
   hipEvent_t e0, e1;
 };
+// One profile per STREAM (round 4: it was one per process, so a second host thread driving another handle could not
+// open its own and interleaved its launches into the first one's -- the header promises that different handles may be
+// driven from different host threads).  The table is guarded by a mutex; a launch costs one lookup while any profile is
+// open and one relaxed load while none is.
 struct ProfileState {
-  bool open = false;
-  hipStream_t stream = nullptr;
   std::vector<LaunchRecord> records;
-  std::vector<hipEvent_t> pool;  // recycled events
 };
-static ProfileState g_prof;
+static std::mutex g_prof_mu;
+static std::map<hipStream_t, ProfileState> g_profs;       // open profiles, by stream
+static std::vector<hipEvent_t> g_prof_pool;               // recycled events (guarded by g_prof_mu)
+static std::atomic<int> g_prof_open{0};
 static const char* const kClassNames[] = {
     "k_gate<1> scale (diagonal subset)", "k_gate<2> 2x2 butterfly", "k_gate<4> 4x4 butterfly",
     "k_gate_shuffle<1,1> lane 1q", "k_gate_shuffle<1,2> lane 2q", "k_gate_shuffle<2,1> lane+reg 2q",
     "k_tile fused pass"};
 constexpr int kNumClasses = 7;
 
-static hipEvent_t prof_event() {
-  if (!g_prof.pool.empty()) {
-    hipEvent_t e = g_prof.pool.back();
-    g_prof.pool.pop_back();
+static hipEvent_t prof_event_locked() {
+  if (!g_prof_pool.empty()) {
+    hipEvent_t e = g_prof_pool.back();
+    g_prof_pool.pop_back();
     return e;
   }
   hipEvent_t e = nullptr;
@@ -136,29 +140,33 @@ static hipEvent_t prof_event() {
 }
 
 struct ProfileScope {  // RAII around one launch
-  bool on;
+  bool on = false;
   LaunchRecord rec;
   ProfileScope(int cls, double bytes, hipStream_t stream, bool streaming, double hbm_bytes = -1.0) {
-    on = g_prof.open && g_prof.stream == stream;
-    if (!on) return;
+    if (g_prof_open.load(std::memory_order_relaxed) == 0) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (g_profs.find(stream) == g_profs.end()) return;
     rec.cls = cls;
     rec.bytes = bytes;
     rec.streaming = streaming;
     rec.hbm_bytes = hbm_bytes < 0 ? bytes : hbm_bytes;
-    rec.e0 = prof_event();
-    rec.e1 = prof_event();
+    rec.e0 = prof_event_locked();
+    rec.e1 = prof_event_locked();
     if (!rec.e0 || !rec.e1) {               // no event available: keep what we got for reuse, time nothing
-      if (rec.e0) g_prof.pool.push_back(rec.e0);
-      if (rec.e1) g_prof.pool.push_back(rec.e1);
-      on = false;
+      if (rec.e0) g_prof_pool.push_back(rec.e0);
+      if (rec.e1) g_prof_pool.push_back(rec.e1);
       return;
     }
+    on = true;
     (void)hipEventRecord(rec.e0, stream);
   }
   void done(hipStream_t stream) {
     if (!on) return;
     (void)hipEventRecord(rec.e1, stream);
-    g_prof.records.push_back(rec);
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    auto it = g_profs.find(stream);
+    if (it != g_profs.end()) it->second.records.push_back(rec);
+    else { g_prof_pool.push_back(rec.e0); g_prof_pool.push_back(rec.e1); }   // (the profile was closed meanwhile)
   }
 };
 

@@ -27,7 +27,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <list>
+#include <map>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -1312,36 +1314,46 @@ int qsim_time_end(qsim_chunk* c, float* elapsed_ms) {
 int qsim_profile_begin(qsim_chunk* c) {
   int rc = check_chunk(c, "qsim_profile_begin");
   if (rc) return rc;
-  if (g_prof.open) return fail(QSIM_ERR_INVALID, "a profile is already open");
   HIP_TRY(hipSetDevice(c->device));
-  g_prof.records.clear();
-  g_prof.stream = c->stream;
-  g_prof.open = true;
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  if (g_profs.count(c->stream)) return fail(QSIM_ERR_INVALID, "a profile is already open on this chunk's stream");
+  g_profs[c->stream];
+  g_prof_open.fetch_add(1);
   return QSIM_OK;
 }
 
 int qsim_profile_end(qsim_chunk* c, int max_entries, int* n_entries, qsim_profile_entry* out) {
   int rc = check_chunk(c, "qsim_profile_end");
   if (rc) return rc;
-  if (!g_prof.open) return fail(QSIM_ERR_INVALID, "no profile is open");
   if (!n_entries || (!out && max_entries > 0)) return fail(QSIM_ERR_INVALID, "null output");
-  g_prof.open = false;
+  std::vector<LaunchRecord> records;
+  {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    auto it = g_profs.find(c->stream);
+    if (it == g_profs.end()) return fail(QSIM_ERR_INVALID, "no profile is open on this chunk's stream");
+    records.swap(it->second.records);
+    g_profs.erase(it);
+    g_prof_open.fetch_sub(1);
+  }
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  hipError_t sync = hipStreamSynchronize(c->stream);
   uint64_t launches[kNumClasses] = {0}, streaming[kNumClasses] = {0};
   double ms[kNumClasses] = {0}, bytes[kNumClasses] = {0}, hbm[kNumClasses] = {0};
-  for (LaunchRecord& r : g_prof.records) {
+  hipError_t bad = sync;
+  for (LaunchRecord& r : records) {
     float t = 0.f;
-    HIP_TRY(hipEventElapsedTime(&t, r.e0, r.e1));
+    if (bad == hipSuccess) bad = hipEventElapsedTime(&t, r.e0, r.e1);
     launches[r.cls] += 1;
     streaming[r.cls] += r.streaming ? 1 : 0;
     ms[r.cls] += t;
     bytes[r.cls] += r.bytes;
     hbm[r.cls] += r.hbm_bytes;
-    g_prof.pool.push_back(r.e0);
-    g_prof.pool.push_back(r.e1);
   }
-  g_prof.records.clear();
+  {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    for (LaunchRecord& r : records) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
+  }
+  if (bad != hipSuccess) return fail(QSIM_ERR_HIP, "qsim_profile_end: %s", hipGetErrorString(bad));
   int n = 0;
   for (int cls = 0; cls < kNumClasses; ++cls) {
     if (!launches[cls]) continue;

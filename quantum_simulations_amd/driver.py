@@ -104,10 +104,12 @@ class Driver:
 
     def get_state_dict(self, result: SimulationResult) -> dict[int, complex]:
         """{idx: amplitude} of the rows v3 keeps (|re| > 1e-15 or |im| > 1e-15).  The rows are selected on the device
-        (qsim_export_nonzero), so a sparse state of many qubits costs two passes over HBM and a few bytes over PCIe."""
+        (qsim_export_nonzero), so a sparse state of many qubits costs two passes over HBM (count, then append with the
+        counted capacity) and a few bytes over PCIe."""
         state = result.final_state
-        if state.count_nonzero(PRUNE_EPS) <= self.SPARSE_EXPORT_MAX_ROWS:
-            rows = state.export_nonzero(PRUNE_EPS)
+        count = state.count_nonzero(PRUNE_EPS)
+        if count <= self.SPARSE_EXPORT_MAX_ROWS:
+            rows = state.export_nonzero(PRUNE_EPS, capacity=count)
             if rows is not None:
                 return {int(i): complex(a) for i, a in zip(*rows)}
         psi = state.download()

@@ -321,6 +321,16 @@ class DistributedEngine:
         # the shard lives in a receive buffer in slab layout (None: in "state", index order).
         self.fuse_relayout = fuse_relayout
         self._state_in = None
+        # Memory per rank: the shard + the send buffer + TWO receive buffers that take turns (a pass that reads the shard
+        # from one receive buffer stores its own slab into the other) = 4 shard-sized allocations with fused re-layouts
+        # (64 GiB at 30 local qubits), 3 without.  Claimed here, not in the middle of a circuit.
+        if not self.dry and hasattr(self.backend, "tensor"):
+            try:
+                for name in ("buf0", "buf1") + (("buf2",) if fuse_relayout else ()):
+                    self.backend.tensor(name)
+            except RuntimeError as e:        # torch's out-of-memory error is a RuntimeError
+                raise MemoryError(f"rank {rank}: no room for the exchange buffers ({4 if fuse_relayout else 3} x "
+                                  f"{16 << self.k} bytes per rank are needed with fuse_relayout={fuse_relayout}): {e}") from e
 
     # ---- layout ------------------------------------------------------------------------
     @property

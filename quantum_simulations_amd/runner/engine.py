@@ -101,13 +101,27 @@ class SingleGpuEngine:
                 ts.append(dev.time_end())
             return float(np.median(ts))
 
+        def moved_bytes(fn) -> float:
+            """bytes the launch(es) of one gate really move (the library's own per-launch accounting: 32 B per amplitude
+            a launch touches -- all of them when a diagonal / control bit lies inside a 128-B line)"""
+            dev.profile_begin()
+            fn()
+            return float(sum(e["hbm_bytes"] for e in dev.profile_end()))
+
         def row(label, targets, fn, nbytes, note=None) -> dict:
             ms = [timed(lambda q=q: fn(q)) for q in targets]
             fr = [nbytes / (t * 1e-3) / 8.0e12 for t in ms]
+            moved = [moved_bytes(lambda q=q: fn(q)) for q in targets]
+            mf = [b / (t * 1e-3) / 8.0e12 for b, t in zip(moved, ms)]
             out = {"targets": [int(q) for q in targets], "algorithmic_bytes_per_gate": nbytes,
                    "ms_per_target": [round(t, 4) for t in ms], "frac_of_8TBps": [round(f, 4) for f in fr],
+                   # the same launches by the bytes they MOVE: where it exceeds frac_of_8TBps (sub-line control / diagonal
+                   # bits: every 128-B line moves for half or a quarter of the amplitudes) the algorithmic fraction is
+                   # at its floor, not the kernel slow
+                   "moved_bytes_per_target": [int(b) for b in moved], "moved_frac": [round(f, 4) for f in mf],
                    "min_frac": round(min(fr), 4), "median_frac": round(float(np.median(fr)), 4),
-                   "max_frac": round(max(fr), 4), "gate_apps_per_s_median": round(1e3 / float(np.median(ms)), 1)}
+                   "max_frac": round(max(fr), 4), "min_moved_frac": round(min(mf), 4),
+                   "gate_apps_per_s_median": round(1e3 / float(np.median(ms)), 1)}
             if note:
                 out["note"] = note
             return out

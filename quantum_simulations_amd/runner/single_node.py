@@ -76,7 +76,7 @@ def _plan_fingerprint(steps, k: int, use_fusion: bool, use_staging: bool, stagin
             "steps_sha256": h.hexdigest()}
 
 
-def _check_plan_sidecar(work: Path, first_step: int, fingerprint: dict) -> None:
+def _check_plan_sidecar(work: Path, first_step: int, fingerprint: dict, committed_manifest: dict | None = None) -> None:
     """`done_steps` of a checkpoint indexes the step list of the run that wrote it.  This build records the planner
     flags next to `wal.json` (`plan.json`) and refuses to resume under a different plan.  A checkpoint WITHOUT the
     sidecar was written by the reference (wenbo_engine/runner/single_node.py:78-138 knows no sidecar) or by a round-1
@@ -101,6 +101,16 @@ def _check_plan_sidecar(work: Path, first_step: int, fingerprint: dict) -> None:
                              "run is staged: staged step lists differ between the implementations; refusing to resume")
         if first_step > fingerprint["n_steps"]:
             raise ValueError(f"checkpoint in {work} has {first_step} steps done, this plan has only {fingerprint['n_steps']}")
+        # the one planner input the directory itself records: the manifest of the committed buffer holds the chunk_size
+        # (and qubit count) the state was written with -- the unstaged step list depends on k = log2(chunk_size), so a
+        # resume with another chunk_size would index another step list.  `use_fusion` is recorded nowhere in
+        # a reference-written directory and cannot be verified: the caller vouches for it.
+        if committed_manifest is not None:
+            for key, now in (("chunk_size", 1 << fingerprint["k"]), ("n_qubits", fingerprint.get("n_qubits"))):
+                was = committed_manifest.get(key)
+                if was is not None and now is not None and int(was) != int(now):
+                    raise ValueError(f"checkpoint in {work} was written with {key} = {was}, this run uses {now}: the step "
+                                     "lists differ; refusing to resume")
         plan_path.write_text(json.dumps(fingerprint))
         return
     if saved != fingerprint:
@@ -139,7 +149,14 @@ def run(circuit_dict: dict, work_dir: str | Path | None = None, chunk_size: int 
         log = WAL(work / "wal.json", circuit_dict=cd)   # raises on a different circuit
         first_step = log.done_steps
         fingerprint = _plan_fingerprint(steps, k, use_fusion, use_staging, staging_method)
-        _check_plan_sidecar(work, first_step, fingerprint)
+        committed_manifest = None
+        if first_step > 0:
+            try:
+                from quantum_simulations_amd.storage.block_store import read_manifest
+                committed_manifest = read_manifest(work / f"state_{log.committed_buf}")
+            except (OSError, ValueError):
+                committed_manifest = None           # (load_to_device below reports a missing / broken buffer)
+        _check_plan_sidecar(work, first_step, fingerprint, committed_manifest)
         first_step = min(first_step, len(steps))
     if first_step > 0:
         state = load_to_device(work / f"state_{log.committed_buf}", device)

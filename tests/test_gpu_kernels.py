@@ -570,6 +570,53 @@ def test_streaming_policy_on_small_views_of_a_large_allocation(hip):
     dev.close()
 
 
+def test_profiles_are_per_stream_and_usable_from_two_host_threads(hip):
+    """qsim_profile_begin / end keep one profile per STREAM (it was one per process although handles on
+    different streams may be driven from different host threads): two handles on two streams, each profiled from its
+    own thread at the same time, each sees exactly its own launches; a second begin on an open stream fails."""
+    import threading
+
+    import torch
+    k = 12
+    results, errors = {}, []
+
+    def work(name, n_gates):
+        try:
+            stream = torch.cuda.Stream()
+            t = torch.zeros(2 << k, dtype=torch.float64, device="cuda:0")
+            t[0] = 1.0
+            torch.cuda.synchronize()
+            c = hip.DeviceChunk.wrap_pointer(t.data_ptr(), k, 0, stream=stream.cuda_stream, keep=t)
+            c.profile_begin()
+            with pytest.raises(ValueError, match="already open"):
+                c.profile_begin()
+            barrier.wait(timeout=60)                 # both profiles are open before either launches
+            for q in range(n_gates):
+                c.apply_1q(q % k, orc.gate_matrix("H"))
+            barrier.wait(timeout=60)                 # ... and both have launched before either closes
+            prof = c.profile_end()
+            results[name] = (sum(e["launches"] for e in prof), c.norm2())
+            with pytest.raises(ValueError, match="no profile"):
+                c.profile_end()
+            c.close()
+        except Exception as e:                       # noqa: BLE001 (reported by the main thread)
+            errors.append((name, repr(e)))
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+
+    barrier = threading.Barrier(2)
+    threads = [threading.Thread(target=work, args=("a", 5)), threading.Thread(target=work, args=("b", 9))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    assert results["a"][0] == 5 and results["b"][0] == 9, results
+    assert abs(results["a"][1] - 1.0) < 1e-12 and abs(results["b"][1] - 1.0) < 1e-12
+
+
 @pytest.mark.parametrize("n", [9, 12, 15])
 def test_fused_phase_runs_keep_their_order(hip, n):
     """Phase gates that share a predicate are merged per register group (OPC_DIAGR) and written out

@@ -161,3 +161,23 @@ def test_complex64_transfers_round_on_the_device_like_numpy():
         dev.download_c64((1 << k) - 10, 11)
     dev.close()
     back.close()
+
+
+def test_resume_without_sidecar_checks_the_manifest_chunk_size(tmp_path):
+    """a checkpoint directory without plan.json (written by the reference) is accepted for unstaged plans on
+    the caller's word -- but the committed buffer's manifest records the chunk_size the state was written with, and the
+    unstaged step list depends on it: a resume with another chunk_size is refused instead of indexing another step list."""
+    import pytest
+
+    from quantum_simulations_amd.runner.single_node import _check_plan_sidecar
+    fp = {"k": 4, "use_fusion": False, "use_staging": False, "staging_method": None, "n_steps": 9, "steps_sha256": "x"}
+    with pytest.raises(ValueError, match="chunk_size = 8"):
+        _check_plan_sidecar(tmp_path, 3, fp, {"chunk_size": 8, "n_qubits": 6})
+    assert not (tmp_path / "plan.json").exists()
+    _check_plan_sidecar(tmp_path, 3, fp, {"chunk_size": 16, "n_qubits": 6})          # same chunk_size: accepted, sidecar written
+    assert (tmp_path / "plan.json").exists()
+    (tmp_path / "plan.json").unlink()
+    _check_plan_sidecar(tmp_path, 3, fp, None)                                         # no readable manifest: as before
+    (tmp_path / "plan.json").unlink()
+    with pytest.raises(ValueError, match="staged"):
+        _check_plan_sidecar(tmp_path, 3, dict(fp, use_staging=True, staging_method="heuristic"), {"chunk_size": 16})
