@@ -61,6 +61,10 @@ int qsim_device_count(int* count) {
   return QSIM_OK;
 }
 
+static bool parts_pending(const qsim_chunk* c) { return c->pending && c->pending->mode != PendingLast::kNone; }
+// (error paths and re-initialisation: the chunk's contents are unspecified while pieces are pending, so dropping them loses nothing)
+static void drop_pending(qsim_chunk* c) { if (c->pending) c->pending->mode = PendingLast::kNone; }
+
 static qsim_chunk* new_chunk() {
   qsim_chunk* c = new qsim_chunk();
   std::memset(c, 0, sizeof *c);
@@ -144,6 +148,7 @@ void* qsim_device_ptr(const qsim_chunk* c) { return c ? (void*)c->amp : nullptr;
 int qsim_init_zero(qsim_chunk* c, int set_amp0) {
   int rc = check_chunk(c, "qsim_init_zero");
   if (rc) return rc;
+  drop_pending(c);
   HIP_TRY(hipSetDevice(c->device));
   hipLaunchKernelGGL(k_fill_zero, dim3(stream_grid(amps(c))), dim3(kBlock), 0, c->stream, c->amp, amps(c), set_amp0);
   HIP_TRY(hipGetLastError());
@@ -311,6 +316,7 @@ int qsim_apply_ops_unfused(qsim_chunk* c, int n_ops, const int32_t* nq, const in
 int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats) {
   int rc = validate_ops(c, n_ops, nq, qubits, mats);
   if (rc) return rc;
+  if (parts_pending(c)) return fail(QSIM_ERR_INVALID, "qsim_apply_ops: slab pieces of a split qsim_apply_ops_io call are pending on this chunk");
   if (n_ops < 2 || c->k < kTileMinChunk || c->k > kTileMaxQubits) {
     c->last_passes = n_ops;
     return qsim_apply_ops_unfused(c, n_ops, nq, qubits, mats);
@@ -971,6 +977,7 @@ int qsim_comm_relayout_fused(qsim_comm* cm, qsim_chunk* shard, qsim_chunk* send,
   if ((rc = qsim_apply_ops_io(shard, before->n_ops, before->nq, before->qubits, before->mats, &io, &passes_before))) return rc;
   int32_t n_parts = 0, n_runs = 0;
   uint64_t run_amps = 0, run_off[64];
+  struct Guard { qsim_chunk* c; bool armed; ~Guard() { if (armed) drop_pending(c); } } guard{shard, true};   // an error below leaves nothing pending
   if ((rc = qsim_apply_ops_io_parts(shard, &n_parts, &n_runs, &run_amps, run_off, 64))) return rc;
   if (p.n_peers * n_runs > 64) return fail(QSIM_ERR_INVALID, "internal: %d transfers in one piece", p.n_peers * n_runs);
   for (int j = 0; j < n_parts; ++j) {

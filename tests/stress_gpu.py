@@ -48,7 +48,17 @@ while time.time() - t0 < budget:
         dst.init_zero(False)
         keep.init_zero(False)
         dev.init_zero(False)
-        dev.apply_ops_io(ops, src=(src, bits_in), dst=(dst, bits_out, keep if own >= 0 else None, own))
+        split = int(rng.integers(0, 4))       # 0: one call stores the slabs; else the split form, pieces stored in random order
+        dev.apply_ops_io(ops, src=(src, bits_in), dst=(dst, bits_out, keep if own >= 0 else None, own), parts=-(1 << split) if split else 0)
+        if split:
+            parts = dev.pending_parts()
+            slab_amps = (1 << n) >> m
+            seen = np.zeros(slab_amps, dtype=np.int32)
+            for j in rng.permutation(len(parts)):
+                dev.store_part(int(j))
+                for off, cnt in parts[int(j)]:
+                    seen[off:off + cnt] += 1
+            assert np.all(seen == 1), ("pieces do not tile the slab", n, seed, bits_out, parts)
         g0, g1 = dst.download(), keep.download()
         slab = (1 << n) >> m
         for d, w in enumerate(slabs(want, bits_out)):
@@ -103,10 +113,29 @@ while time.time() - t1 < budget * 0.5:
     dev = DeviceChunk.from_numpy(psi0)
     dev.apply_ops(ops, fused=True)
     err = float(np.max(np.abs(dev.download() - want)))
-    dev.close()
     worst = max(worst, err)
     assert err < 1e-10, ("big", n, seed, err)
+    # the same list with its slab-storing pass cut into pieces (qsim_ops_io::dst_parts), real 2^20 floor from 23 qubits on
+    m = int(rng.integers(1, 4))
+    bits = [int(b) for b in rng.choice(np.arange(3, n), size=m, replace=False)]
+    own = int(rng.integers(0, 1 << m))
+    dst, keep = DeviceChunk.empty(n), DeviceChunk.empty(n)
+    dev.upload(psi0)
+    dev.apply_ops_io(ops, dst=(dst, bits, keep, own), parts=4 if n >= 23 else -4)
+    parts = dev.pending_parts()
+    for j in rng.permutation(len(parts)):
+        dev.store_part(int(j))
+    idx = np.arange(1 << n)
+    pat = sum(((idx >> b) & 1) << i for i, b in enumerate(bits))
+    slab = (1 << n) >> m
+    g0, g1 = dst.download(), keep.download()
+    for d in range(1 << m):
+        e2 = float(np.max(np.abs((g1 if d == own else g0)[d * slab:(d + 1) * slab] - want[pat == d])))
+        worst = max(worst, e2)
+        assert e2 < 1e-10, ("big split", n, seed, bits, own, d, len(parts), e2)
+    for c in (dev, dst, keep):
+        c.close()
     big_cases += 1
-    print(f"... large case {big_cases}: n = {n}, {len(ops)} ops, err {err:.2e}", flush=True)
+    print(f"... large case {big_cases}: n = {n}, {len(ops)} ops, err {err:.2e}; slabs over {bits} in {len(parts)} piece(s) x {len(parts[0])} run(s)", flush=True)
 print(f"stress ok: {big_cases} large cases (21-25 qubits, fused) in {time.time() - t1:.0f} s")
 print(f"stress ok: {cases} random cases in {time.time() - t0:.0f} s, worst |diff| = {worst:.2e}")
