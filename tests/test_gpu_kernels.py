@@ -572,21 +572,20 @@ def test_streaming_policy_on_small_views_of_a_large_allocation(hip):
 
 def test_profiles_are_per_stream_and_usable_from_two_host_threads(hip):
     """qsim_profile_begin / end keep one profile per STREAM (it was one per process although handles on
-    different streams may be driven from different host threads): two handles on two streams, each profiled from its
-    own thread at the same time, each sees exactly its own launches; a second begin on an open stream fails."""
+    different streams may be driven from different host threads): two handles on two streams -- the library's own and
+    the default stream (`qsim_wrap` with a null stream) -- each profiled from its own thread at the same time, each sees
+    exactly its own launches; a second begin on an open stream fails."""
     import threading
-
-    import torch
     k = 12
     results, errors = {}, []
+    own = hip.DeviceChunk.zero_state(k)                      # the library's stream
+    mem = hip.DeviceChunk.zero_state(k)
+    mem.sync()
+    other = hip.DeviceChunk.wrap_pointer(mem.device_ptr, k, 0, stream=0, keep=mem)    # the same kind of memory on the default stream
+    barrier = threading.Barrier(2)
 
-    def work(name, n_gates):
+    def work(name, c, n_gates):
         try:
-            stream = torch.cuda.Stream()
-            t = torch.zeros(2 << k, dtype=torch.float64, device="cuda:0")
-            t[0] = 1.0
-            torch.cuda.synchronize()
-            c = hip.DeviceChunk.wrap_pointer(t.data_ptr(), k, 0, stream=stream.cuda_stream, keep=t)
             c.profile_begin()
             with pytest.raises(ValueError, match="already open"):
                 c.profile_begin()
@@ -598,7 +597,6 @@ def test_profiles_are_per_stream_and_usable_from_two_host_threads(hip):
             results[name] = (sum(e["launches"] for e in prof), c.norm2())
             with pytest.raises(ValueError, match="no profile"):
                 c.profile_end()
-            c.close()
         except Exception as e:                       # noqa: BLE001 (reported by the main thread)
             errors.append((name, repr(e)))
             try:
@@ -606,8 +604,7 @@ def test_profiles_are_per_stream_and_usable_from_two_host_threads(hip):
             except Exception:
                 pass
 
-    barrier = threading.Barrier(2)
-    threads = [threading.Thread(target=work, args=("a", 5)), threading.Thread(target=work, args=("b", 9))]
+    threads = [threading.Thread(target=work, args=("a", own, 5)), threading.Thread(target=work, args=("b", other, 9))]
     for t in threads:
         t.start()
     for t in threads:
@@ -615,6 +612,8 @@ def test_profiles_are_per_stream_and_usable_from_two_host_threads(hip):
     assert not errors, errors
     assert results["a"][0] == 5 and results["b"][0] == 9, results
     assert abs(results["a"][1] - 1.0) < 1e-12 and abs(results["b"][1] - 1.0) < 1e-12
+    for c in (own, other, mem):
+        c.close()
 
 
 @pytest.mark.parametrize("n", [9, 12, 15])
