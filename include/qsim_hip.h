@@ -105,21 +105,22 @@ typedef struct {
   qsim_chunk* dst; int32_t dst_m; int32_t dst_bits[3];
   qsim_chunk* dst_own; int32_t own_pattern;
   int32_t dst_parts;   /* 0: the slabs are stored by this call.  P = 2, 4, 8 (split form, dst != NULL): this call launches
-                        * everything but the storing of the slabs, which is cut into up to P PIECES -- piece j = the same
-                        * sub-range(s) of every slab (the highest index bits that are neither slab bits nor tile bits of the
-                        * storing pass have the value j; runs keep >= 2^20 amplitudes, so small shards get fewer pieces) --
-                        * and the caller stores them with qsim_apply_ops_io_part(c, j), in any order, posting the exchange
-                        * of piece j (all peers at once: every link busy) while the later pieces are still computed.  The
-                        * storing pass runs as one partial launch per piece, or as qsim_pack_all pieces when it cannot be
-                        * fused.  (-P: the same without the 2^20 floor: tests.) */
+                        * everything but the storing of the slabs, which is cut into PIECES -- piece j = the j-th of 2^nb <= P
+                        * equal contiguous sub-ranges of every slab (pieces keep >= 2^20 amplitudes, so small shards get
+                        * fewer; the count depends only on the chunk size, m and P: qsim_split_piece_count, the same on
+                        * every rank whatever its own pass plan) -- and the caller stores them with
+                        * qsim_apply_ops_io_part(c, j), posting the exchange of piece j (all peers at once: every link
+                        * busy) while later pieces are still computed.  The storing pass runs as partial launches when the
+                        * piece bits are no tile bits of it (else as one launch with the first piece), or as qsim_pack_all
+                        * pieces when it cannot be fused.  (-P: the same without the 2^20 floor: tests.) */
 } qsim_ops_io;
 int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits,
                       const double* mats, const qsim_ops_io* io, int* n_passes);
-/* Pieces of the pending split call: piece j of EVERY slab d is the n_runs runs [d * 2^(k - m) + run_offsets[j * n_runs + r],
- * + run_amps) of the send / receive buffers (a tile bit above the piece bits cuts a piece into two runs). */
-int qsim_apply_ops_io_parts(const qsim_chunk* c, int32_t* n_parts, int32_t* n_runs, uint64_t* run_amps,
-                            uint64_t* run_offsets, int capacity);
+/* Pieces of the pending split call: piece j of EVERY slab d is [d * 2^(k - m) + j * piece_amps, + piece_amps) of the send /
+ * receive buffers; n_launches = the partial launches this chunk's pass is cut into (<= n_parts; 0: stored already). */
+int qsim_apply_ops_io_parts(const qsim_chunk* c, int32_t* n_parts, uint64_t* piece_amps, int32_t* n_launches);
 int qsim_apply_ops_io_part(qsim_chunk* c, int part);
+int qsim_split_piece_count(int n_local_qubits, int m, int dst_parts);   /* the piece rule as a pure function */
 /* The host planner of the fused passes WITHOUT a device (used by the CPU tests): plans the op list
  * for a 2^n_local_qubits chunk and writes one QSIM_PASS_IMAGE_BYTES pass image per planned pass to `out`
  * (layout = the kernel-argument block of k_tile, csrc/tile_kernel.h: record count, tile size T, tile high

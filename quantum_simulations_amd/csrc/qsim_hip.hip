@@ -655,19 +655,16 @@ int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t
   }
   if (parts) {
     // split form: the slabs are stored piece by piece by qsim_apply_ops_io_part -- partial launches of the planned last
-    // pass, or (nothing fusable) qsim_pack_all pieces of the final state, or nothing (stored already: one part)
+    // pass, or (nothing fusable) qsim_pack_all pieces of the final state, or nothing (stored already)
     PendingLast* p = c->pending ? c->pending : (c->pending = new PendingLast());
     const bool stashed = p->mode == PendingLast::kStashed;
     p->mode = stashed ? PendingLast::kTile : (fio.fused_out ? PendingLast::kDone : PendingLast::kPack);
     p->m = io->dst_m;
     for (int i = 0; i < io->dst_m; ++i) p->bits[i] = io->dst_bits[i];
     p->dst = io->dst; p->dst_own = io->dst_own; p->own_pattern = io->own_pattern;
-    p->launched = 0;
-    const int min_run_bits = io->dst_parts < 0 ? 3 : 20;        // (negative: tests cut small shards too)
+    const int min_piece_bits = io->dst_parts < 0 ? kTileLow : 20;        // (negative: tests cut small shards too)
     const int want = io->dst_parts < 0 ? -io->dst_parts : io->dst_parts;
-    if (p->mode == PendingLast::kTile) plan_parts(p, c->k, want, p->a.h, p->T - kTileLow, min_run_bits);
-    else if (p->mode == PendingLast::kPack) plan_parts(p, c->k, want, nullptr, 0, min_run_bits);
-    else plan_parts(p, c->k, 1, nullptr, 0);
+    plan_parts(p, c->k, want, p->mode == PendingLast::kTile ? p->a.h : nullptr, p->mode == PendingLast::kTile ? p->T - kTileLow : 0, min_piece_bits);
     if (p->mode == PendingLast::kPack) ++passes;
   } else if (io->dst && !fio.fused_out) {     // not fused: pack passes
     if ((rc = slabs_all(c, io->dst_m, io->dst_bits, io->dst, io->own_pattern, 0, 1, true, "qsim_apply_ops_io"))) return rc;
@@ -688,51 +685,56 @@ int qsim_apply_ops_io_part(qsim_chunk* c, int part) {
   if (rc) return rc;
   PendingLast* p = c->pending;
   if (!p || p->mode == PendingLast::kNone) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_part: no split op list is pending on this chunk");
-  if (part < 0 || part >= p->n_parts) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_part: part %d out of range", part);
-  if ((p->launched >> part) & 1) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_part: part %d has been stored already", part);
+  const int n_parts = 1 << p->nb;
+  if (part < 0 || part >= n_parts) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_part: piece %d out of range", part);
+  if ((p->stored >> part) & 1) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_part: piece %d has been stored already", part);
   HIP_TRY(hipSetDevice(c->device));
   if (p->mode == PendingLast::kTile) {
-    TileArgs a = p->a;
-    a.nfix = (uint8_t)p->nfix;
-    a.fix_or = 0;
-    for (int i = 0; i < p->nfix; ++i) {
-      int below = 0;
-      for (int j = 0; j < p->T - kTileLow; ++j) below += a.h[j] < p->fix[i];
-      a.fix_pos[i] = (uint8_t)(p->fix[i] - below);
-      if ((part >> i) & 1) a.fix_or |= 1ull << p->fix[i];
-    }
-    if ((rc = launch_tile_any(a, p->T, c, c->stream, p->alg_bytes / (double)p->n_parts))) return rc;
-  } else if (p->mode == PendingLast::kPack) {
-    // (the pieces of qsim_pack_all are the values of the top non-slab index bits: the same cut as plan_parts without a tile)
-    if ((rc = slabs_all(c, p->m, p->bits, p->dst, p->own_pattern, part, p->n_parts, true, "qsim_apply_ops_io_part"))) return rc;
-    if (p->own_pattern >= 0) {
-      // the own slab goes to the receive buffer: its piece as a plain copy of the packed form is not available (skipped
-      // above), so the per-pattern pack writes it; once, with the first part
-      if (p->launched == 0) {
-        const uint64_t slab = 1ull << (c->k - p->m);
-        if ((rc = qsim_pack_bits(c, p->m, p->bits, p->own_pattern, p->dst_own, (uint64_t)p->own_pattern * slab))) return rc;
+    // the partial launch that holds this piece: the top nb_free piece bits select it, it stores 2^(nb - nb_free) pieces
+    const int g = part >> (p->nb - p->nb_free);
+    if (!((p->launched >> g) & 1)) {
+      TileArgs a = p->a;
+      a.nfix = (uint8_t)p->nb_free;
+      a.fix_or = 0;
+      for (int i = 0; i < p->nb_free; ++i) {
+        const int bit = p->piece_bit[p->nb - p->nb_free + i];            // ascending: the top nb_free piece bits
+        int below = 0;
+        for (int j = 0; j < p->T - kTileLow; ++j) below += a.h[j] < bit;
+        a.fix_pos[i] = (uint8_t)(bit - below);
+        if ((g >> i) & 1) a.fix_or |= 1ull << bit;
+        if (bit >= c->k || bit < kTileLow) return fail(QSIM_ERR_INVALID, "internal: piece bit %d", bit);
       }
+      if ((rc = launch_tile_any(a, p->T, c, c->stream, p->alg_bytes / (double)(1 << p->nb_free)))) return rc;
+      p->launched |= 1u << g;
+    }
+  } else if (p->mode == PendingLast::kPack) {
+    // (the pieces of qsim_pack_all are the values of the top non-slab index bits: the same cut)
+    if ((rc = slabs_all(c, p->m, p->bits, p->dst, p->own_pattern, part, n_parts, true, "qsim_apply_ops_io_part"))) return rc;
+    if (p->own_pattern >= 0 && p->stored == 0) {            // the own slab goes to the receive buffer whole, with the first piece
+      const uint64_t slab = 1ull << (c->k - p->m);
+      if ((rc = qsim_pack_bits(c, p->m, p->bits, p->own_pattern, p->dst_own, (uint64_t)p->own_pattern * slab))) return rc;
     }
   }
-  p->launched |= 1u << part;
-  if (p->launched == (p->n_parts >= 32 ? ~0u : (1u << p->n_parts) - 1u)) p->mode = PendingLast::kNone;
+  p->stored |= 1u << part;
+  if (p->stored == (1u << n_parts) - 1u) p->mode = PendingLast::kNone;
   return QSIM_OK;
 }
 
-// The pieces of the pending split op list: piece j of EVERY slab is the runs [run_offsets[j * n_runs + r], + run_amps),
-// r < n_runs, of the slab (amplitudes, relative to the slab's start d * 2^(k - m) in the send / receive buffers).
-int qsim_apply_ops_io_parts(const qsim_chunk* c, int32_t* n_parts, int32_t* n_runs, uint64_t* run_amps, uint64_t* run_offsets,
-                            int capacity) {
+// The pieces of the pending split op list: piece j of EVERY slab d is [d * 2^(k - m) + j * piece_amps, + piece_amps) of the
+// send / receive buffers.  n_parts depends only on (k, m, dst_parts): the same on every rank.
+int qsim_apply_ops_io_parts(const qsim_chunk* c, int32_t* n_parts, uint64_t* piece_amps, int32_t* n_launches) {
   if (!c || !c->pending || c->pending->mode == PendingLast::kNone) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_parts: no split op list is pending on this chunk");
   const PendingLast* p = c->pending;
-  if (n_parts) *n_parts = p->n_parts;
-  if (n_runs) *n_runs = p->n_runs;
-  if (run_amps) *run_amps = p->run_amps;
-  if (run_offsets) {
-    if (capacity < p->n_parts * p->n_runs) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_parts: %d offsets do not fit", p->n_parts * p->n_runs);
-    for (int i = 0; i < p->n_parts * p->n_runs; ++i) run_offsets[i] = p->run_off[(size_t)i];
-  }
+  if (n_parts) *n_parts = 1 << p->nb;
+  if (piece_amps) *piece_amps = (1ull << (c->k - p->m)) >> p->nb;
+  if (n_launches) *n_launches = p->mode == PendingLast::kTile ? (1 << p->nb_free) : (p->mode == PendingLast::kPack ? (1 << p->nb) : 0);
   return QSIM_OK;
+}
+
+// (k, m, pieces asked for) -> pieces made: the rule of the split form as a pure function (schedulers, dry runs, tests)
+int qsim_split_piece_count(int n_local_qubits, int m, int dst_parts) {
+  if (m < 1 || m > 3 || m > n_local_qubits || dst_parts == 0) return 1;
+  return 1 << piece_bits_for(n_local_qubits, m, dst_parts < 0 ? -dst_parts : dst_parts, dst_parts < 0 ? kTileLow : 20);
 }
 
 // ---- multi-GPU reach of the C ABI (comm_rccl.h) ---------------------------------------------------
@@ -975,24 +977,21 @@ int qsim_comm_relayout_fused(qsim_comm* cm, qsim_chunk* shard, qsim_chunk* send,
   io.dst_parts = n_pieces == 1 ? -1 : n_pieces;            // (always the split form: -1 = one piece)
   int passes_before = 0, passes_after = 0;
   if ((rc = qsim_apply_ops_io(shard, before->n_ops, before->nq, before->qubits, before->mats, &io, &passes_before))) return rc;
-  int32_t n_parts = 0, n_runs = 0;
-  uint64_t run_amps = 0, run_off[64];
+  int32_t n_parts = 0;
+  uint64_t piece_amps = 0;
   struct Guard { qsim_chunk* c; bool armed; ~Guard() { if (armed) drop_pending(c); } } guard{shard, true};   // an error below leaves nothing pending
-  if ((rc = qsim_apply_ops_io_parts(shard, &n_parts, &n_runs, &run_amps, run_off, 64))) return rc;
-  if (p.n_peers * n_runs > 64) return fail(QSIM_ERR_INVALID, "internal: %d transfers in one piece", p.n_peers * n_runs);
+  if ((rc = qsim_apply_ops_io_parts(shard, &n_parts, &piece_amps, nullptr))) return rc;
   for (int j = 0; j < n_parts; ++j) {
     if ((rc = qsim_apply_ops_io_part(shard, j))) return rc;
     HIP_TRY(hipEventRecord(cm->ev[j], shard->stream));
     HIP_TRY(hipStreamWaitEvent(cm->xfer_stream, cm->ev[j], 0));
-    int32_t peers[64];
-    uint64_t offs[64];
-    int n = 0;
-    for (int i = 0; i < p.n_peers; ++i)
-      for (int r = 0; r < n_runs; ++r) {
-        peers[n] = loopback ? cm->rank : p.peers[i];
-        offs[n++] = p.offs[i] + run_off[j * n_runs + r];
-      }
-    if ((rc = comm_exchange(cm, n, peers, send->amp, offs, recv->amp, offs, run_amps, cm->xfer_stream))) return rc;
+    int32_t peers[8];
+    uint64_t offs[8];
+    for (int i = 0; i < p.n_peers; ++i) {
+      peers[i] = loopback ? cm->rank : p.peers[i];
+      offs[i] = p.offs[i] + (u64)j * piece_amps;
+    }
+    if ((rc = comm_exchange(cm, p.n_peers, peers, send->amp, offs, recv->amp, offs, piece_amps, cm->xfer_stream))) return rc;
   }
   HIP_TRY(hipEventRecord(cm->ev[15], cm->xfer_stream));
   HIP_TRY(hipStreamWaitEvent(shard->stream, cm->ev[15], 0));

@@ -1115,11 +1115,15 @@ struct FusedIo {
 };
 
 // The slab-storing pass of an op list whose caller asked for the split form (qsim_ops_io::dst_parts): planned, not yet
-// launched.  It is stored PIECE by piece: piece j = the amplitudes whose `nfix` fixed index bits (the highest index bits
-// that are neither slab bits nor tile bits of the pass) have the value j -- the same sub-range(s) of EVERY slab, so the
-// exchange of piece j uses all links at once while the pieces behind it are still being computed.  kTile: one partial
-// launch of the pass per piece; kPack (nothing fusable: the state is final in the chunk): one qsim_pack_all piece;
-// kDone: the pass could not be split and has stored everything already (one part, nothing to launch).
+// launched.  The slabs are stored PIECE by piece: piece j = the j-th of 2^nb equal contiguous sub-ranges of EVERY slab
+// (the top nb index bits that are not slab bits have the value j), so the exchange of piece j uses all links at once
+// while the pieces behind it are still being computed.  The cut depends ONLY on (k, m, pieces asked for): every rank of a
+// multi-GPU run cuts alike whatever its own pass plan looks like (ranks plan different op lists: rank-bit phases,
+// controlled gates with a global control) -- the k-th transfer between two ranks always has the same size on both sides.
+// What a rank's plan decides is only how early its pieces are ready: kTile -- the top `nb_free` <= nb piece bits are not
+// tile bits of the pass, which then runs as 2^nb_free partial launches (a launch stores 2^(nb - nb_free) pieces at once;
+// nb_free = 0: one launch, everything ready with the first piece); kPack (nothing fusable: the state is final in the
+// chunk): one qsim_pack_all piece per call; kDone: stored already (passes that cannot be launched in part).
 struct PendingLast {
   enum Mode { kNone = 0, kStashed, kTile, kPack, kDone };   // kStashed: launch_planned has put the pass here, the caller's slab description is still missing
   int mode = kNone;
@@ -1131,49 +1135,30 @@ struct PendingLast {
   qsim_chunk* dst = nullptr;
   qsim_chunk* dst_own = nullptr;
   int own_pattern = -1;
-  int n_parts = 1;                   // 2^nfix
-  int nfix = 0;
-  int fix[3] = {0, 0, 0};            // the fixed index bits, ascending (piece j: bit i of j <-> fix[i])
-  int n_runs = 1;                    // contiguous runs of one piece inside a slab (tile bits above the lowest fixed bit split it)
-  u64 run_amps = 0;
-  std::vector<u64> run_off;          // [part * n_runs + r]: offset of the run inside every slab, in amplitudes
-  unsigned launched = 0;             // bit j: piece j has been stored
+  int nb = 0;                        // piece bits: 2^nb pieces
+  int piece_bit[3] = {0, 0, 0};      // the top nb non-slab index bits, ascending (piece j: bit i of j <-> piece_bit[i])
+  int nb_free = 0;                   // kTile: how many of them, from the top, are no tile bits of the pass
+  unsigned stored = 0;               // bit j: piece j has been handed out
+  unsigned launched = 0;             // kTile: bit g: partial launch g (the top nb_free bits of the piece number) is queued
 };
 
-// Which pieces the slab-storing pass is cut into: up to `want` (2, 4, 8) pieces over the highest index bits that are
-// neither slab bits nor (tile != nullptr) high bits of the pass, as long as a run keeps >= 2^min_run_bits amplitudes and
-// a piece has at most 8 runs per slab.
-static void plan_parts(PendingLast* p, int k, int want, const uint8_t* tile_high, int n_tile_high, int min_run_bits = 20) {
+// 2^nb pieces for a request of `want` (1, 2, 4, 8): as many as asked for while a piece keeps >= 2^min_piece_bits amplitudes.
+static int piece_bits_for(int k, int m, int want, int min_piece_bits) {
+  int nb = 0;
+  while (nb < 3 && (2 << nb) <= want && (k - m) - (nb + 1) >= min_piece_bits && (k - m) - (nb + 1) >= kTileLow) ++nb;
+  return nb;
+}
+
+static void plan_parts(PendingLast* p, int k, int want, const uint8_t* tile_high, int n_tile_high, int min_piece_bits) {
   auto is_slab = [&](int b) { for (int i = 0; i < p->m; ++i) if (p->bits[i] == b) return true; return false; };
   auto is_tile = [&](int b) { for (int j = 0; j < n_tile_high; ++j) if (tile_high[j] == b) return true; return false; };
-  auto sigma = [&](int b) { int s = b; for (int i = 0; i < p->m; ++i) s -= p->bits[i] < b; return s; };   // position in the slab offset
-  int want_bits = 0;
-  while ((2 << want_bits) <= want && want_bits < 3) ++want_bits;
-  p->nfix = 0; p->n_parts = 1; p->n_runs = 1; p->run_amps = 1ull << (k - p->m); p->run_off.assign(1, 0);
-  for (int nb = want_bits; nb >= 1; --nb) {
-    int fix[3], found = 0, above_tile = 0;
-    for (int b = k - 1; b >= kTileLow && found < nb; --b) {
-      if (is_slab(b)) continue;
-      if (is_tile(b)) { ++above_tile; continue; }
-      fix[found++] = b;
-    }
-    if (found < nb) continue;
-    const int fmin = fix[nb - 1];
-    if (sigma(fmin) < min_run_bits || above_tile > 3) continue;
-    p->nfix = nb; p->n_parts = 1 << nb; p->n_runs = 1 << above_tile; p->run_amps = 1ull << sigma(fmin);
-    for (int i = 0; i < nb; ++i) p->fix[i] = fix[nb - 1 - i];          // ascending
-    std::vector<int> tb;                                                  // tile bits above fmin, ascending
-    for (int b = fmin + 1; b < k; ++b) if (!is_slab(b) && is_tile(b)) tb.push_back(b);
-    p->run_off.assign((size_t)p->n_parts * p->n_runs, 0);
-    for (int j = 0; j < p->n_parts; ++j)
-      for (int r = 0; r < p->n_runs; ++r) {
-        u64 off = 0;
-        for (int i = 0; i < nb; ++i) if ((j >> i) & 1) off |= 1ull << sigma(p->fix[i]);
-        for (size_t t = 0; t < tb.size(); ++t) if ((r >> t) & 1) off |= 1ull << sigma(tb[t]);
-        p->run_off[(size_t)j * p->n_runs + r] = off;
-      }
-    return;
-  }
+  p->nb = piece_bits_for(k, p->m, want, min_piece_bits);
+  int top[3], found = 0;
+  for (int b = k - 1; b >= 0 && found < p->nb; --b) if (!is_slab(b)) top[found++] = b;    // descending
+  for (int i = 0; i < p->nb; ++i) p->piece_bit[i] = top[p->nb - 1 - i];
+  p->nb_free = 0;
+  while (p->nb_free < p->nb && !is_tile(top[p->nb_free])) ++p->nb_free;
+  p->stored = p->launched = 0;
 }
 
 // One planned pass on its way to the device: buffers, the re-layout of the op list's ends, launch.

@@ -189,13 +189,13 @@ class DeviceChunk:
         return passes.value
 
     def pending_parts(self) -> list:
-        """Pieces of the pending split `apply_ops_io`: [[(offset, amplitudes), ...runs], ...pieces] -- piece j of EVERY
-        slab d is those runs of [d * slab, (d + 1) * slab) in the send / receive buffers (qsim_apply_ops_io_parts)."""
-        n_parts, n_runs, run = C.c_int32(), C.c_int32(), C.c_uint64()
-        offs = np.zeros(64, dtype=np.uint64)
-        _lib.check(_lib.load().qsim_apply_ops_io_parts(self._h, C.byref(n_parts), C.byref(n_runs), C.byref(run),
-                                                       offs.ctypes.data_as(C.c_void_p), 64))
-        return [[(int(offs[j * n_runs.value + r]), int(run.value)) for r in range(n_runs.value)] for j in range(n_parts.value)]
+        """Pieces of the pending split `apply_ops_io`: [(offset, amplitudes), ...] -- piece j of EVERY slab d is that
+        range of [d * slab, (d + 1) * slab) in the send / receive buffers (qsim_apply_ops_io_parts).  The cut depends only
+        on (k, m, parts asked for): every rank gets the same list."""
+        n_parts, amps_, launches = C.c_int32(), C.c_uint64(), C.c_int32()
+        _lib.check(_lib.load().qsim_apply_ops_io_parts(self._h, C.byref(n_parts), C.byref(amps_), C.byref(launches)))
+        self.last_split_launches = launches.value
+        return [(j * int(amps_.value), int(amps_.value)) for j in range(n_parts.value)]
 
     def store_part(self, part: int) -> None:
         _lib.check(_lib.load().qsim_apply_ops_io_part(self._h, int(part)))
@@ -300,6 +300,12 @@ class DeviceChunk:
         b = np.asarray(bits, dtype=np.int32)
         _lib.check(_lib.load().qsim_unpack_all(self._h, len(b), b.ctypes.data_as(C.c_void_p), buf._h, int(skip_pattern),
                                                int(piece), int(n_pieces)))
+
+
+def split_piece_count(k: int, m: int, parts: int) -> int:
+    """Pieces the split form of `apply_ops_io` cuts every slab into (qsim_split_piece_count: a pure function of the chunk
+    size, the slab bits' count and the pieces asked for -- no device needed)."""
+    return int(_lib.load().qsim_split_piece_count(int(k), int(m), int(parts)))
 
 
 def device_count() -> int:

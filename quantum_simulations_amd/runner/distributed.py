@@ -172,6 +172,18 @@ class HipShardBackend:
         self._tensors.clear()
 
 
+def split_pieces(k: int, m: int, parts: int) -> list:
+    """[(offset, amplitudes)] of the pieces the split form of qsim_apply_ops_io cuts every slab into -- the library's rule
+    (qsim_split_piece_count: as many as asked for while a piece keeps >= 2^20 amplitudes; negative `parts`: no floor)
+    restated for backends without the library (dry runs, the CPU test double; tests compare the two)."""
+    want, floor = abs(parts), (20 if parts > 0 else 3)
+    nb = 0
+    while nb < 3 and (2 << nb) <= want and (k - m) - (nb + 1) >= floor:
+        nb += 1
+    piece = (1 << (k - m)) >> nb
+    return [(j * piece, piece) for j in range(1 << nb)]
+
+
 class Plan:
     """Step lists for successive executions (the staging layout carries over between them).
     `start_mappings[i]` is the planned layout execution i starts from; `execute` refuses a plan whose
@@ -226,10 +238,7 @@ class DryBackend:
                 self._check(side[1], 0, 1)
         self.local_passes += 1
         if dst is not None and parts:
-            # the pieces the library would cut the slab-storing pass into: up to `parts`, each run >= 2^20 amplitudes
-            slab = 1 << (self.k - len(dst[1]))
-            n = max(1, min(parts, slab >> 20))
-            self._parts = [[(j * (slab // n), slab // n)] for j in range(n)]
+            self._parts = split_pieces(self.k, len(dst[1]), parts)
         return 1
 
     def pending_parts(self) -> list:
@@ -593,10 +602,13 @@ class DistributedEngine:
             # the unfused path below handles it.)  The receive buffer must not be the one the shard currently lives in (a
             # one-pass op list would read and write it at once): a third buffer takes turns.
             # What overlaps what: the slab-storing pass is cut into up to `relayout_pieces` PIECES
-            # (the same sub-range(s) of every slab: qsim_ops_io::dst_parts) and the exchange of piece j -- one group
+            # (the j-th equal sub-range of every slab: qsim_ops_io::dst_parts) and the exchange of piece j -- one group
             # with all 2^m - 1 peers, every link busy -- is posted as soon as piece j is stored, so it travels while the
             # pieces behind it are computed; only the first piece's compute and the last piece's transfer are exposed on
-            # the send side.  The first pass AFTER the exchange still waits for every piece (its tiles read all slabs).
+            # the send side.  The cut depends only on (k, m, pieces): all ranks post the same messages in the same order
+            # whatever their own pass plans look like (a rank whose last pass holds a piece bit as a tile bit has all its
+            # pieces ready at once: it overlaps less, it does not post differently).  The first pass AFTER the exchange
+            # still waits for every piece (its tiles read all slabs).
             rname = "buf2" if (self._state_in is not None and self._state_in[0] == "buf1") else "buf1"
             ops, self._pending = self._pending, []
             self._passes += self.backend.apply_ops(ops, src=self._state_in, dst=("buf0", loc, rname, mine),
@@ -604,9 +616,9 @@ class DistributedEngine:
             self._state_in = None
             timer = self._comm_timer(send)
             posted = []
-            for j, runs in enumerate(self.backend.pending_parts()):
+            for j, (off, cnt) in enumerate(self.backend.pending_parts()):
                 self.backend.store_part(j)
-                posted.append(self._post("buf0", rname, [(peer, d * slab + 2 * off, 2 * cnt) for d, peer in peers for off, cnt in runs]))
+                posted.append(self._post("buf0", rname, [(peer, d * slab + 2 * off, 2 * cnt) for d, peer in peers]))
             for pst in posted:
                 self._finish(pst)
             self._comm_done(timer)

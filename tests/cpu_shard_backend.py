@@ -85,9 +85,9 @@ class CpuShardBackend:
             slab = 1 << (self.k - len(bits))
             if parts:
                 # split form (qsim_ops_io::dst_parts): nothing is stored yet -- piece j of every slab by store_part(j)
-                n = max(1, min(abs(parts), slab))
-                self._split = (buf, list(bits), own_buf, own, n, self._c("state").copy())
-                self._parts = [[(j * (slab // n), slab // n)] for j in range(n)]
+                from quantum_simulations_amd.runner.distributed import split_pieces
+                self._parts = split_pieces(self.k, len(bits), parts)
+                self._split = (buf, list(bits), own_buf, own, len(self._parts), self._c("state").copy())
                 self._stored = set()
             else:
                 self.pack_all(bits, buf, own)

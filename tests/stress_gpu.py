@@ -56,8 +56,8 @@ while time.time() - t0 < budget:
             seen = np.zeros(slab_amps, dtype=np.int32)
             for j in rng.permutation(len(parts)):
                 dev.store_part(int(j))
-                for off, cnt in parts[int(j)]:
-                    seen[off:off + cnt] += 1
+                off, cnt = parts[int(j)]
+                seen[off:off + cnt] += 1
             assert np.all(seen == 1), ("pieces do not tile the slab", n, seed, bits_out, parts)
         g0, g1 = dst.download(), keep.download()
         slab = (1 << n) >> m
@@ -123,6 +123,7 @@ while time.time() - t1 < budget * 0.5:
     dev.upload(psi0)
     dev.apply_ops_io(ops, dst=(dst, bits, keep, own), parts=4 if n >= 23 else -4)
     parts = dev.pending_parts()
+    dev_launches = dev.last_split_launches
     for j in rng.permutation(len(parts)):
         dev.store_part(int(j))
     idx = np.arange(1 << n)
@@ -136,6 +137,6 @@ while time.time() - t1 < budget * 0.5:
     for c in (dev, dst, keep):
         c.close()
     big_cases += 1
-    print(f"... large case {big_cases}: n = {n}, {len(ops)} ops, err {err:.2e}; slabs over {bits} in {len(parts)} piece(s) x {len(parts[0])} run(s)", flush=True)
+    print(f"... large case {big_cases}: n = {n}, {len(ops)} ops, err {err:.2e}; slabs over {bits} in {len(parts)} piece(s), {dev_launches} partial launch(es)", flush=True)
 print(f"stress ok: {big_cases} large cases (21-25 qubits, fused) in {time.time() - t1:.0f} s")
 print(f"stress ok: {cases} random cases in {time.time() - t0:.0f} s, worst |diff| = {worst:.2e}")

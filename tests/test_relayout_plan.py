@@ -85,13 +85,12 @@ def test_python_engine_posts_the_planned_transfers(world, k, pairs):
     n = k + world.bit_length() - 1
     for rank in range(world):
         for fuse in (False, True):
-            # unfused: the pack / transfer / unpack pipeline in pieces; fused (slab bits above the line bits): whole slabs
-            # in one group, like the plan with one piece
+            # unfused: the pack / transfer / unpack pipeline in pieces; fused (slab bits above the line bits; round 4): the
+            # slab-storing pass is cut into the same pieces and each piece's group is posted as soon as it is stored
             eng = DistributedEngine(n, world, rank, backend=DryBackend(k), init_process_group=False, fuse_relayout=fuse)
             eng.relayout(pairs)
-            fused = fuse and min(min(p) for p in pairs) >= 3
-            plan = relayout_plan(rank, world, k, [min(p) for p in pairs], [max(p) - k for p in pairs],
-                                 1 if fused else eng.relayout_pieces)
+            plan = relayout_plan(rank, world, k, [min(p) for p in pairs], [max(p) - k for p in pairs], eng.relayout_pieces)
+            assert eng.trace_posts == plan["pieces"] >= 2
             posted = [(peer, sent // 16) for _, peer, sent, _ in eng.trace]
             want = [(peer, plan["piece_amps"]) for _ in range(plan["pieces"]) for peer in plan["peers"]]
             assert posted == want, (rank, fuse, posted[:8], want[:8])
@@ -108,3 +107,24 @@ def test_bad_arguments():
         relayout_plan(0, 4, 10, [10], [0])
     with pytest.raises(ValueError):
         relayout_plan(0, 4, 10, [1], [0], 3)
+
+
+def test_split_piece_rule_is_the_same_in_python_and_in_the_library():
+    """The pieces a fused re-layout is cut into depend only on (local qubits, slab bits, pieces asked for): the library's
+    rule (qsim_split_piece_count, a pure function: no device) and its restatement for the dry-run / CPU backends
+    (runner/distributed.split_pieces) agree, pieces tile the slab, and the real floor keeps them >= 2^20 amplitudes."""
+    from quantum_simulations_amd.kernel.device import split_piece_count
+    from quantum_simulations_amd.runner.distributed import split_pieces
+    for k in range(4, 34):
+        for m in (1, 2, 3):
+            if m >= k:
+                continue
+            for parts in (1, 2, 4, 8, -1, -2, -4, -8):
+                pieces = split_pieces(k, m, parts)
+                assert len(pieces) == split_piece_count(k, m, parts), (k, m, parts)
+                assert len(pieces) <= abs(parts) and len(pieces) & (len(pieces) - 1) == 0
+                assert [off for off, _ in pieces] == [j * pieces[0][1] for j in range(len(pieces))]
+                assert sum(cnt for _, cnt in pieces) == 1 << (k - m)
+                if parts > 1 and len(pieces) > 1:
+                    assert pieces[0][1] >= 1 << 20
+    assert len(split_pieces(30, 3, 4)) == 4 and len(split_pieces(30, 1, 8)) == 8 and len(split_pieces(22, 2, 4)) == 1
