@@ -113,9 +113,19 @@ typedef struct {
                         * busy) while later pieces are still computed.  The storing pass runs as partial launches when the
                         * piece bits are no tile bits of it (else as one launch with the first piece), or as qsim_pack_all
                         * pieces when it cannot be fused.  (-P: the same without the 2^20 floor: tests.) */
+  int32_t src_parts;   /* 0: the source is complete when this call is made.  P = 2, 4, 8 (src != NULL): the source arrives in the
+                        * pieces of the same rule (the sender's dst_parts = P over the same slab bits): this call plans the op
+                        * list and launches NOTHING; the caller announces every piece with qsim_apply_ops_io_load(c, j) once
+                        * its transfer is ordered on the chunk's stream.  The first pass runs as partial launches over the
+                        * tiles whose source pieces are there (when the top piece bits are no tile bits of it; else whole,
+                        * with the last piece), everything else of the list with the last piece -- the receive side of a
+                        * fused re-layout overlaps its first pass with the links.  With dst_parts too, the slab pieces of
+                        * the destination are stored (qsim_apply_ops_io_part) after the last load. */
 } qsim_ops_io;
 int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits,
                       const double* mats, const qsim_ops_io* io, int* n_passes);
+int qsim_apply_ops_io_load(qsim_chunk* c, int part);
+int qsim_apply_ops_io_source_parts(const qsim_chunk* c, int32_t* n_parts, uint64_t* piece_amps, int32_t* n_launches);
 /* Pieces of the pending split call: piece j of EVERY slab d is [d * 2^(k - m) + j * piece_amps, + piece_amps) of the send /
  * receive buffers; n_launches = the partial launches this chunk's pass is cut into (<= n_parts; 0: stored already). */
 int qsim_apply_ops_io_parts(const qsim_chunk* c, int32_t* n_parts, uint64_t* piece_amps, int32_t* n_launches);
@@ -190,8 +200,12 @@ int qsim_comm_exchange(qsim_comm* comm, int n_peers, const int32_t* peers, const
  * queued on the chunks' stream so far and BESIDE what is queued on it later (the next piece of a fused re-layout being
  * computed); qsim_comm_join makes a chunk's stream wait for every background transfer posted so far. */
 int qsim_comm_exchange_bg(qsim_comm* comm, int n_peers, const int32_t* peers, const qsim_chunk* send,
-                          const uint64_t* send_off, qsim_chunk* recv, const uint64_t* recv_off, uint64_t count_amps);
+                          const uint64_t* send_off, qsim_chunk* recv, const uint64_t* recv_off, uint64_t count_amps,
+                          uint32_t* ticket);                 /* ticket: may be NULL */
 int qsim_comm_join(qsim_comm* comm, qsim_chunk* c);
+/* ... or only for the exchange `ticket` names (and those posted before it): the pieces of a re-layout are consumed as they
+ * arrive (qsim_apply_ops_io_load), later pieces still on the links. */
+int qsim_comm_wait(qsim_comm* comm, qsim_chunk* c, uint32_t ticket);
 /* qsim_swap_global_local ACROSS GPUs: local qubit local_bits[i] of this rank's shard trades places
  * with rank bit global_bits[i] (qubit k + global_bits[i]) for i < m <= 3 -- the merged all-to-all form
  * of a staging SWAP list (staging.py:136-152).  Every rank of the communicator calls it with the same

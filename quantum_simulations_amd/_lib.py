@@ -60,6 +60,8 @@ SIGNATURES = {
     "qsim_last_pass_count": (C.c_int, [_P]),
     "qsim_apply_ops_io": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.POINTER(C.c_int)]),
     "qsim_apply_ops_io_part": (C.c_int, [_P, C.c_int]),
+    "qsim_apply_ops_io_load": (C.c_int, [_P, C.c_int]),
+    "qsim_apply_ops_io_source_parts": (C.c_int, [_P, _P, _P, _P]),
     "qsim_apply_ops_io_parts": (C.c_int, [_P, _P, _P, _P]),
     "qsim_split_piece_count": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "qsim_apply_1q_pair": (C.c_int, [_P, _P, _P]),
@@ -79,7 +81,8 @@ SIGNATURES = {
     "qsim_comm_rank": (C.c_int, [_P]),
     "qsim_comm_world": (C.c_int, [_P]),
     "qsim_comm_exchange": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_uint64]),
-    "qsim_comm_exchange_bg": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_uint64]),
+    "qsim_comm_exchange_bg": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint32)]),
+    "qsim_comm_wait": (C.c_int, [_P, _P, C.c_uint32]),
     "qsim_comm_join": (C.c_int, [_P, _P]),
     "qsim_comm_relayout": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int]),
     "qsim_comm_relayout_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
@@ -109,7 +112,7 @@ class OpsIo(C.Structure):
     """qsim_ops_io (include/qsim_hip.h): buffers a re-layout is fused with at the ends of an op list."""
     _fields_ = [("src", C.c_void_p), ("src_m", C.c_int32), ("src_bits", C.c_int32 * 3),
                 ("dst", C.c_void_p), ("dst_m", C.c_int32), ("dst_bits", C.c_int32 * 3),
-                ("dst_own", C.c_void_p), ("own_pattern", C.c_int32), ("dst_parts", C.c_int32)]
+                ("dst_own", C.c_void_p), ("own_pattern", C.c_int32), ("dst_parts", C.c_int32), ("src_parts", C.c_int32)]
 
 
 class OpList(C.Structure):

@@ -80,6 +80,8 @@ struct qsim_comm {
   int rank, world, device;
   hipStream_t xfer_stream;     // re-layout pieces travel here while the next piece is packed on the chunk's stream
   hipEvent_t ev[16];           // piece s: ev[2s] = packed, ev[2s+1] = received
+  hipEvent_t ev_bg[16];        // background exchanges (qsim_comm_exchange_bg): ticket t -> ev_bg[t % 16], recorded behind its group
+  uint32_t bg_posted;          // tickets handed out so far
 };
 
 static int check_comm(const qsim_comm* c, const char* what) {

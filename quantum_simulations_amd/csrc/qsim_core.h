@@ -35,6 +35,7 @@ struct qsim_chunk {
   int last_passes;       // HBM passes of the last qsim_apply_ops
   u64 span_bytes;        // size of the allocation the chunk lives in (cache-policy choice)
   struct PendingLast* pending;   // split form of qsim_apply_ops_io: the slab-storing pass, planned but not yet launched (owned)
+  struct DeferredIo* deferred;   // an op list whose source arrives in pieces (qsim_ops_io::src_parts): planned, not yet launched (owned)
 };
 
 static const int kMaxDevices = 16;

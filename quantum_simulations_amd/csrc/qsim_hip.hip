@@ -49,6 +49,24 @@ typedef unsigned long long u64;
 #include "misc_kernels.h"
 #include "comm_rccl.h"
 
+// An op list whose SOURCE arrives in pieces (qsim_ops_io::src_parts: the receive side of a fused re-layout): planned and
+// prepared at the call, launched as the pieces are announced (qsim_apply_ops_io_load) -- the first pass as partial launches
+// over the tiles whose source pieces are there, the rest when the source is complete.
+struct DeferredIo {
+  bool active = false;
+  bool tiles = false;               // tile passes (else: chunk too small / no ops: gate by gate after the source is complete)
+  int n_ops = 0;
+  std::vector<int32_t> nq, qubits;  // the op list (kept for the gate-by-gate case)
+  std::vector<double> mats;
+  qsim_ops_io io;
+  FusedIo fio;
+  std::vector<CachedPass> passes;   // prepared passes (buffers in)
+  int nb = 0;                       // 2^nb source pieces: the top nb index bits that are no source slab bits
+  int piece_bit[3] = {0, 0, 0};     // ascending
+  int nb_free = 0;                  // the first pass runs as 2^nb_free partial launches (0: whole, after the last piece)
+  unsigned announced = 0, launched = 0;
+};
+
 // ------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -61,9 +79,14 @@ int qsim_device_count(int* count) {
   return QSIM_OK;
 }
 
-static bool parts_pending(const qsim_chunk* c) { return c->pending && c->pending->mode != PendingLast::kNone; }
+static bool parts_pending(const qsim_chunk* c) {
+  return (c->pending && c->pending->mode != PendingLast::kNone) || (c->deferred && c->deferred->active);
+}
 // (error paths and re-initialisation: the chunk's contents are unspecified while pieces are pending, so dropping them loses nothing)
-static void drop_pending(qsim_chunk* c) { if (c->pending) c->pending->mode = PendingLast::kNone; }
+static void drop_pending(qsim_chunk* c) {
+  if (c->pending) c->pending->mode = PendingLast::kNone;
+  if (c->deferred) c->deferred->active = false;
+}
 
 static qsim_chunk* new_chunk() {
   qsim_chunk* c = new qsim_chunk();
@@ -134,6 +157,7 @@ int qsim_destroy(qsim_chunk* c) {
   if (c->have_events) { (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); }
   if (c->scratch) (void)hipFree(c->scratch);
   delete c->pending;
+  delete c->deferred;
   if (c->owns_memory && c->amp) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->amp);
@@ -580,6 +604,74 @@ int qsim_swap_global_local(qsim_chunk* const* chunks, int n_chunks, const int32_
   return QSIM_OK;
 }
 
+// The slab-storing end of an op list whose tile passes (all but a stashed last one) have been queued: the split form's
+// bookkeeping (the pieces are stored by qsim_apply_ops_io_part), or the pack passes of a list that could not fuse them.
+static int finish_out_side(qsim_chunk* c, const qsim_ops_io* io, FusedIo& fio) {
+  int rc = QSIM_OK;
+  if (io->dst && io->dst_parts != 0) {
+    // split form: the slabs are stored piece by piece by qsim_apply_ops_io_part -- partial launches of the planned last
+    // pass, or (nothing fusable) qsim_pack_all pieces of the final state, or nothing (stored already)
+    PendingLast* p = c->pending ? c->pending : (c->pending = new PendingLast());
+    const bool stashed = p->mode == PendingLast::kStashed;
+    p->mode = stashed ? PendingLast::kTile : (fio.fused_out ? PendingLast::kDone : PendingLast::kPack);
+    p->m = io->dst_m;
+    for (int i = 0; i < io->dst_m; ++i) p->bits[i] = io->dst_bits[i];
+    p->dst = io->dst; p->dst_own = io->dst_own; p->own_pattern = io->own_pattern;
+    const int min_piece_bits = io->dst_parts < 0 ? kTileLow : 20;        // (negative: tests cut small shards too)
+    const int want = io->dst_parts < 0 ? -io->dst_parts : io->dst_parts;
+    plan_parts(p, c->k, want, p->mode == PendingLast::kTile ? p->a.h : nullptr, p->mode == PendingLast::kTile ? p->T - kTileLow : 0, min_piece_bits);
+  } else if (io->dst && !fio.fused_out) {     // not fused: pack passes
+    if ((rc = slabs_all(c, io->dst_m, io->dst_bits, io->dst, io->own_pattern, 0, 1, true, "qsim_apply_ops_io"))) return rc;
+    if (io->own_pattern >= 0) {
+      const uint64_t slab = 1ull << (c->k - io->dst_m);
+      if ((rc = qsim_pack_bits(c, io->dst_m, io->dst_bits, io->own_pattern, io->dst_own, (uint64_t)io->own_pattern * slab))) return rc;
+    }
+  }
+  return QSIM_OK;
+}
+
+// qsim_ops_io::src_parts: plan now, launch as the source pieces are announced (qsim_apply_ops_io_load)
+static int apply_ops_io_deferred(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,
+                                 const qsim_ops_io* io, const FusedIo& fio_in, const std::vector<FusedOp>& ops, bool tiles, int* n_passes) {
+  DeferredIo* d = c->deferred ? c->deferred : (c->deferred = new DeferredIo());
+  *d = DeferredIo();
+  d->tiles = tiles;
+  d->n_ops = n_ops;
+  d->io = *io;
+  d->fio = fio_in;
+  const int want = io->src_parts < 0 ? -io->src_parts : io->src_parts;
+  d->nb = piece_bits_for(c->k, io->src_m, want, io->src_parts < 0 ? kTileLow : 20);
+  auto is_slab = [&](int b) { for (int i = 0; i < io->src_m; ++i) if (io->src_bits[i] == b) return true; return false; };
+  int top[3] = {0, 0, 0}, found = 0;
+  for (int b = c->k - 1; b >= 0 && found < d->nb; --b) if (!is_slab(b)) top[found++] = b;
+  for (int i = 0; i < d->nb; ++i) d->piece_bit[i] = top[d->nb - 1 - i];
+  int passes = 0, rc = QSIM_OK;
+  if (io->src && !d->fio.src) ++passes;                     // the source cannot be read by a tile pass: unpack pieces
+  if (tiles) {
+    int p = 0;
+    if ((rc = run_fused(c, ops, &p, &d->fio, n_ops, nq, qubits, mats, &d->passes))) return rc;
+    passes += p;
+    if (d->fio.src && !d->fio.fused_in) return fail(QSIM_ERR_INVALID, "internal: the first pass did not take the source buffer");
+    // the first pass in partial launches: when it reads the source itself, is not also the slab-storing pass of a split
+    // / fused destination, and the top piece bits are no tile bits of it
+    const bool first_stores = d->passes.size() == 1 && io->dst != nullptr;
+    if (d->fio.src && !first_stores && !d->passes.empty() && d->passes[0].T == kTileBitsMax) {
+      auto is_tile = [&](int b) { for (int j = 0; j < kTileBitsMax - kTileLow; ++j) if (d->passes[0].a.h[j] == b) return true; return false; };
+      while (d->nb_free < d->nb && !is_tile(top[d->nb_free])) ++d->nb_free;
+    }
+  } else {
+    d->nq.assign(nq, nq + n_ops);
+    d->qubits.assign(qubits, qubits + 2 * (size_t)n_ops);
+    d->mats.assign(mats, mats + 32 * (size_t)n_ops);
+    passes += n_ops;
+  }
+  if (io->dst && !d->fio.fused_out) ++passes;
+  d->active = true;
+  c->last_passes = passes;
+  if (n_passes) *n_passes = passes;
+  return QSIM_OK;
+}
+
 // Op list with a re-layout fused into its ends (staging.py:136-152 SWAP lists): the FIRST fused pass reads
 // the state from io->src in the slab layout of qsim_pack_all over io->src_bits (what an all-to-all left in the receive
 // buffer) instead of a separate unpack pass, the LAST one stores it into io->dst in the slab layout over io->dst_bits
@@ -636,9 +728,10 @@ int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t
     for (int i = 0; i < io->dst_m; ++i) fio.out.bits[i] = io->dst_bits[i];
   }
   const bool parts = io->dst && io->dst_parts != 0;
-  if (c->pending && c->pending->mode != PendingLast::kNone)
-    return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: slab launches of an earlier split call are pending on this chunk (qsim_apply_ops_io_part)");
+  if (parts_pending(c))
+    return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: pieces of an earlier split call are pending on this chunk (qsim_apply_ops_io_part / _load)");
   fio.parts = parts;
+  if (io->src && io->src_parts != 0) return apply_ops_io_deferred(c, n_ops, nq, qubits, mats, io, fio, ops, tiles, n_passes);
   int passes = 0;
   if (io->src && !fio.src) {           // not fusable: one unpack pass brings the state into the chunk
     if ((rc = slabs_all(c, io->src_m, io->src_bits, const_cast<qsim_chunk*>(io->src), -1, 0, 1, false, "qsim_apply_ops_io"))) return rc;
@@ -653,27 +746,8 @@ int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t
     if ((rc = qsim_apply_ops_unfused(c, n_ops, nq, qubits, mats))) return rc;
     passes += n_ops;
   }
-  if (parts) {
-    // split form: the slabs are stored piece by piece by qsim_apply_ops_io_part -- partial launches of the planned last
-    // pass, or (nothing fusable) qsim_pack_all pieces of the final state, or nothing (stored already)
-    PendingLast* p = c->pending ? c->pending : (c->pending = new PendingLast());
-    const bool stashed = p->mode == PendingLast::kStashed;
-    p->mode = stashed ? PendingLast::kTile : (fio.fused_out ? PendingLast::kDone : PendingLast::kPack);
-    p->m = io->dst_m;
-    for (int i = 0; i < io->dst_m; ++i) p->bits[i] = io->dst_bits[i];
-    p->dst = io->dst; p->dst_own = io->dst_own; p->own_pattern = io->own_pattern;
-    const int min_piece_bits = io->dst_parts < 0 ? kTileLow : 20;        // (negative: tests cut small shards too)
-    const int want = io->dst_parts < 0 ? -io->dst_parts : io->dst_parts;
-    plan_parts(p, c->k, want, p->mode == PendingLast::kTile ? p->a.h : nullptr, p->mode == PendingLast::kTile ? p->T - kTileLow : 0, min_piece_bits);
-    if (p->mode == PendingLast::kPack) ++passes;
-  } else if (io->dst && !fio.fused_out) {     // not fused: pack passes
-    if ((rc = slabs_all(c, io->dst_m, io->dst_bits, io->dst, io->own_pattern, 0, 1, true, "qsim_apply_ops_io"))) return rc;
-    ++passes;
-    if (io->own_pattern >= 0) {
-      const uint64_t slab = 1ull << (c->k - io->dst_m);
-      if ((rc = qsim_pack_bits(c, io->dst_m, io->dst_bits, io->own_pattern, io->dst_own, (uint64_t)io->own_pattern * slab))) return rc;
-    }
-  }
+  if (io->dst && !fio.fused_out) ++passes;                 // a pack pass (whole, or piece by piece)
+  if ((rc = finish_out_side(c, io, fio))) return rc;
   c->last_passes = passes;
   if (n_passes) *n_passes = passes;
   return QSIM_OK;
@@ -717,6 +791,72 @@ int qsim_apply_ops_io_part(qsim_chunk* c, int part) {
   }
   p->stored |= 1u << part;
   if (p->stored == (1u << n_parts) - 1u) p->mode = PendingLast::kNone;
+  return QSIM_OK;
+}
+
+// Receive side of the split form (qsim_ops_io::src_parts): piece `part` of every slab of the source has arrived (its
+// transfer is ordered before this call on the chunk's stream).  Launches what can run: an unpack piece, a partial launch of
+// the first pass whose source pieces are all there, and -- with the last piece -- everything else of the op list.
+int qsim_apply_ops_io_load(qsim_chunk* c, int part) {
+  int rc = check_chunk(c, "qsim_apply_ops_io_load");
+  if (rc) return rc;
+  DeferredIo* d = c->deferred;
+  if (!d || !d->active) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_load: no op list with a split source is pending on this chunk");
+  const int n_parts = 1 << d->nb;
+  if (part < 0 || part >= n_parts) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_load: piece %d out of range", part);
+  if ((d->announced >> part) & 1) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_load: piece %d has been announced already", part);
+  HIP_TRY(hipSetDevice(c->device));
+  struct Guard { qsim_chunk* c; bool armed; ~Guard() { if (armed) drop_pending(c); } } guard{c, true};   // an error leaves nothing pending
+  d->announced |= 1u << part;
+  const qsim_ops_io* io = &d->io;
+  if (!d->fio.src) {                  // unpack mode: this piece goes home now
+    if ((rc = slabs_all(c, io->src_m, io->src_bits, const_cast<qsim_chunk*>(io->src), -1, part, n_parts, false, "qsim_apply_ops_io_load"))) return rc;
+  } else if (d->nb_free > 0) {        // partial launches of the first pass: group g = the top nb_free bits of the piece number
+    const int shift = d->nb - d->nb_free;
+    const int g = part >> shift;
+    const unsigned group = ((1u << (1 << shift)) - 1u) << (g << shift);
+    if ((d->announced & group) == group && !((d->launched >> g) & 1)) {
+      CachedPass& p0 = d->passes[0];
+      TileArgs a = p0.a;
+      a.nfix = (uint8_t)d->nb_free;
+      a.fix_or = 0;
+      for (int i = 0; i < d->nb_free; ++i) {
+        const int bit = d->piece_bit[shift + i];
+        int below = 0;
+        for (int j = 0; j < p0.T - kTileLow; ++j) below += a.h[j] < bit;
+        a.fix_pos[i] = (uint8_t)(bit - below);
+        if ((g >> i) & 1) a.fix_or |= 1ull << bit;
+        if (bit >= c->k || bit < kTileLow) return fail(QSIM_ERR_INVALID, "internal: piece bit %d", bit);
+      }
+      if ((rc = launch_tile_any(a, p0.T, c, c->stream, p0.alg_bytes / (double)(1 << d->nb_free)))) return rc;
+      d->launched |= 1u << g;
+    }
+  }
+  if (d->announced != (n_parts >= 32 ? ~0u : (1u << n_parts) - 1u)) { guard.armed = false; return QSIM_OK; }
+  // the source is complete: the rest of the op list
+  d->active = false;
+  if (d->tiles) {
+    for (size_t i = 0; i < d->passes.size(); ++i) {
+      if (i == 0 && d->nb_free > 0) continue;               // ran in partial launches
+      CachedPass& p = d->passes[i];
+      if ((rc = dispatch_planned(c, p.a, p.T, p.alg_bytes, i + 1 == d->passes.size(), &d->fio))) return rc;
+    }
+  } else {
+    if ((rc = qsim_apply_ops_unfused(c, d->n_ops, d->nq.data(), d->qubits.data(), d->mats.data()))) return rc;
+  }
+  if ((rc = finish_out_side(c, io, d->fio))) return rc;
+  guard.armed = false;
+  return QSIM_OK;
+}
+
+// Source pieces of the pending op list (qsim_ops_io::src_parts): how many, their size, and how many partial launches the
+// first pass takes (0: it runs whole after the last piece).
+int qsim_apply_ops_io_source_parts(const qsim_chunk* c, int32_t* n_parts, uint64_t* piece_amps, int32_t* n_launches) {
+  if (!c || !c->deferred || !c->deferred->active) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_source_parts: nothing pending on this chunk");
+  const DeferredIo* d = c->deferred;
+  if (n_parts) *n_parts = 1 << d->nb;
+  if (piece_amps) *piece_amps = (1ull << (c->k - d->io.src_m)) >> d->nb;
+  if (n_launches) *n_launches = d->nb_free > 0 ? (1 << d->nb_free) : 0;
   return QSIM_OK;
 }
 
@@ -764,6 +904,8 @@ int qsim_comm_init(int device, int rank, int world, const uint8_t id[QSIM_COMM_I
   c->comm = comm; c->rank = rank; c->world = world; c->device = device;
   c->xfer_stream = nullptr;
   for (auto& e : c->ev) e = nullptr;
+  for (auto& e : c->ev_bg) e = nullptr;
+  c->bg_posted = 0;
   *out = c;
   return QSIM_OK;
 }
@@ -773,6 +915,7 @@ int qsim_comm_destroy(qsim_comm* c) {
   (void)hipSetDevice(c->device);
   if (c->xfer_stream) { (void)hipStreamSynchronize(c->xfer_stream); (void)hipStreamDestroy(c->xfer_stream); }
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : c->ev_bg) if (e) (void)hipEventDestroy(e);
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
   delete c;
   return QSIM_OK;
@@ -801,7 +944,7 @@ int qsim_comm_exchange(qsim_comm* cm, int n_peers, const int32_t* peers, const q
 // stream SO FAR; what is queued on the chunks' stream later runs beside it.  qsim_comm_join makes a chunk's stream wait
 // for every background transfer posted so far (the piece pipeline of a fused re-layout: runner/distributed.py).
 int qsim_comm_exchange_bg(qsim_comm* cm, int n_peers, const int32_t* peers, const qsim_chunk* send, const uint64_t* send_off,
-                          qsim_chunk* recv, const uint64_t* recv_off, uint64_t count_amps) {
+                          qsim_chunk* recv, const uint64_t* recv_off, uint64_t count_amps, uint32_t* ticket) {
   int rc = check_comm(cm, "qsim_comm_exchange_bg");
   if (rc || (rc = check_chunk(send, "qsim_comm_exchange_bg")) || (rc = check_chunk(recv, "qsim_comm_exchange_bg"))) return rc;
   if (n_peers < 0 || (n_peers && (!peers || !send_off || !recv_off))) return fail(QSIM_ERR_INVALID, "qsim_comm_exchange_bg: bad peer list");
@@ -815,9 +958,26 @@ int qsim_comm_exchange_bg(qsim_comm* cm, int n_peers, const int32_t* peers, cons
   HIP_TRY(hipSetDevice(cm->device));
   if (!cm->xfer_stream) HIP_TRY(hipStreamCreateWithFlags(&cm->xfer_stream, hipStreamNonBlocking));
   for (auto& e : cm->ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : cm->ev_bg) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(cm->ev[14], send->stream));
   HIP_TRY(hipStreamWaitEvent(cm->xfer_stream, cm->ev[14], 0));
-  return comm_exchange(cm, n_peers, peers, send->amp, send_off, recv->amp, recv_off, count_amps, cm->xfer_stream);
+  if ((rc = comm_exchange(cm, n_peers, peers, send->amp, send_off, recv->amp, recv_off, count_amps, cm->xfer_stream))) return rc;
+  const uint32_t t = cm->bg_posted++;
+  HIP_TRY(hipEventRecord(cm->ev_bg[t % 16], cm->xfer_stream));
+  if (ticket) *ticket = t;
+  return QSIM_OK;
+}
+
+// The chunk's stream waits for background exchange `ticket` (and, transfers of one communicator running in order, for
+// every one posted before it) -- not for later ones: the pieces of a re-layout are consumed as they arrive.
+int qsim_comm_wait(qsim_comm* cm, qsim_chunk* c, uint32_t ticket) {
+  int rc = check_comm(cm, "qsim_comm_wait");
+  if (rc || (rc = check_chunk(c, "qsim_comm_wait"))) return rc;
+  if (ticket >= cm->bg_posted) return fail(QSIM_ERR_INVALID, "qsim_comm_wait: ticket %u has not been handed out", ticket);
+  if (cm->bg_posted - ticket > 16) return qsim_comm_join(cm, c);   // its event has been reused: wait for everything posted
+  HIP_TRY(hipSetDevice(cm->device));
+  HIP_TRY(hipStreamWaitEvent(c->stream, cm->ev_bg[ticket % 16], 0));
+  return QSIM_OK;
 }
 
 int qsim_comm_join(qsim_comm* cm, qsim_chunk* c) {
@@ -992,13 +1152,23 @@ int qsim_comm_relayout_fused(qsim_comm* cm, qsim_chunk* shard, qsim_chunk* send,
       offs[i] = p.offs[i] + (u64)j * piece_amps;
     }
     if ((rc = comm_exchange(cm, p.n_peers, peers, send->amp, offs, recv->amp, offs, piece_amps, cm->xfer_stream))) return rc;
+    HIP_TRY(hipEventRecord(cm->ev[8 + j], cm->xfer_stream));       // piece j has arrived
   }
-  HIP_TRY(hipEventRecord(cm->ev[15], cm->xfer_stream));
-  HIP_TRY(hipStreamWaitEvent(shard->stream, cm->ev[15], 0));
+  // receive side: `after` is planned now (the links are busy meanwhile) and takes the pieces over as they arrive -- its
+  // first pass runs on the tiles whose pieces are there, the rest with the last piece
   std::memset(&io, 0, sizeof io);
   io.src = recv; io.src_m = m; io.own_pattern = -1;
   for (int i = 0; i < m; ++i) io.src_bits[i] = local_bits[i];
+  io.src_parts = n_pieces == 1 ? -1 : n_pieces;
   if ((rc = qsim_apply_ops_io(shard, after->n_ops, after->nq, after->qubits, after->mats, &io, &passes_after))) return rc;
+  int32_t n_in = 0;
+  if ((rc = qsim_apply_ops_io_source_parts(shard, &n_in, nullptr, nullptr))) return rc;
+  if (n_in != n_parts) return fail(QSIM_ERR_INVALID, "internal: %d source pieces for %d sent ones", n_in, n_parts);
+  for (int j = 0; j < n_parts; ++j) {
+    HIP_TRY(hipStreamWaitEvent(shard->stream, cm->ev[8 + j], 0));
+    if ((rc = qsim_apply_ops_io_load(shard, j))) return rc;
+  }
+  guard.armed = false;
   if (n_passes) *n_passes = passes_before + passes_after;
   return QSIM_OK;
 }

@@ -1161,8 +1161,9 @@ static void plan_parts(PendingLast* p, int k, int want, const uint8_t* tile_high
   p->stored = p->launched = 0;
 }
 
-// One planned pass on its way to the device: buffers, the re-layout of the op list's ends, launch.
-static int launch_planned(qsim_chunk* c, TileArgs& a, int T, double alg_bytes, bool first, bool last, FusedIo* io) {
+// One planned pass on its way to the device: buffers and the re-layout of the op list's ends (prepare_planned), then the
+// launch -- or, for the slab-storing pass of a split call, the stash (dispatch_planned).
+static void prepare_planned(qsim_chunk* c, TileArgs& a, int T, bool first, bool last, FusedIo* io) {
   a.amp = c->amp;
   a.amp_out = c->amp;
   a.amp_out_own = nullptr;
@@ -1194,6 +1195,9 @@ static int launch_planned(qsim_chunk* c, TileArgs& a, int T, double alg_bytes, b
       io->fused_out = true;
     }
   }
+}
+
+static int dispatch_planned(qsim_chunk* c, TileArgs& a, int T, double alg_bytes, bool last, FusedIo* io) {
   if (io && last && io->dst && io->parts && io->fused_out && T == kTileBitsMax) {
     PendingLast* p = c->pending ? c->pending : (c->pending = new PendingLast());
     p->mode = PendingLast::kStashed; p->a = a; p->T = T; p->alg_bytes = alg_bytes; p->launched = 0;
@@ -1214,6 +1218,11 @@ static int launch_planned(qsim_chunk* c, TileArgs& a, int T, double alg_bytes, b
   std::fprintf(stderr, "\n");
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return rc;
+}
+
+static int launch_planned(qsim_chunk* c, TileArgs& a, int T, double alg_bytes, bool first, bool last, FusedIo* io) {
+  prepare_planned(c, a, T, first, last, io);
+  return dispatch_planned(c, a, T, alg_bytes, last, io);
 }
 
 // ---- plan cache ---------------------------------------------------------------------------------------------------
@@ -1240,8 +1249,11 @@ static u64 fnv1a(const unsigned char* p, size_t n, u64 h = 1469598103934665603ul
   return h;
 }
 
+// `defer` (an op list whose source arrives in pieces, qsim_ops_io::src_parts): the passes are planned and prepared (buffers
+// in) but not launched; the caller launches them when the source is complete.
 static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_passes, FusedIo* io = nullptr,
-                     int n_ops = 0, const int32_t* nq = nullptr, const int32_t* qubits = nullptr, const double* mats = nullptr) {
+                     int n_ops = 0, const int32_t* nq = nullptr, const int32_t* qubits = nullptr, const double* mats = nullptr,
+                     std::vector<CachedPass>* defer = nullptr) {
   // key of the call (only when the caller handed the raw op list over)
   std::vector<unsigned char> key;
   u64 hash = 0;
@@ -1266,6 +1278,11 @@ static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_pass
     }
     if (!hit.empty()) {
       for (size_t p = 0; p < hit.size(); ++p) {
+        if (defer) {
+          prepare_planned(c, hit[p].a, hit[p].T, p == 0, p + 1 == hit.size(), io);
+          defer->push_back(hit[p]);
+          continue;
+        }
         const int rc = launch_planned(c, hit[p].a, hit[p].T, hit[p].alg_bytes, p == 0, p + 1 == hit.size(), io);
         if (rc) return rc;
       }
@@ -1276,6 +1293,11 @@ static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_pass
   std::vector<CachedPass> made;
   const int rc = plan_fused(c->k, ops, n_passes, [&](TileArgs& a, int T, double alg_bytes, bool first, bool last) {
     if (cacheable) made.push_back(CachedPass{a, T, alg_bytes});      // (before buffers and layouts go in)
+    if (defer) {
+      prepare_planned(c, a, T, first, last, io);
+      defer->push_back(CachedPass{a, T, alg_bytes});
+      return (int)QSIM_OK;
+    }
     return launch_planned(c, a, T, alg_bytes, first, last, io);
   });
   if (rc == QSIM_OK && cacheable && !made.empty()) {

@@ -157,13 +157,16 @@ class DeviceChunk:
         return lib.qsim_last_pass_count(self._h) if fused else len(ops)
 
     # ---- sync / reductions / timing -------------------------------------------------
-    def apply_ops_io(self, ops, src=None, dst=None, parts: int = 0) -> int:
+    def apply_ops_io(self, ops, src=None, dst=None, parts: int = 0, src_parts: int = 0) -> int:
         """`apply_ops` with a re-layout fused into its ends (qsim_apply_ops_io): `src` = (chunk, bits): the state
         is read from that chunk in the slab layout of `pack_all` over `bits`; `dst` = (chunk, bits, own_chunk,
         own_pattern): it is left in `chunk` in slab layout, slab `own_pattern` (>= 0) in `own_chunk`.  Returns the
         HBM passes made.  `parts` = 2, 4, 8 (with `dst`): split form -- the slabs are NOT stored by this call but piece
         by piece by `store_part(j)` for every j < len(`pending_parts()`), so that each piece's exchange can be posted
-        while the later pieces are still computed (negative: no 2^20-amplitude floor on a run, for tests)."""
+        while the later pieces are still computed (negative: no 2^20-amplitude floor on a piece, for tests).
+        `src_parts` (with `src`): the source arrives in the pieces of the same rule: this call only plans; announce every
+        piece with `load_part(j)` once its transfer is ordered on this chunk's stream -- the first pass starts on the
+        tiles whose pieces are there, the rest runs with the last piece."""
         nq, qs, mats = pack_ops(ops) if not (isinstance(ops, tuple) and len(ops) == 3 and isinstance(ops[0], np.ndarray)) else ops
         io = _lib.OpsIo()
         keep = []
@@ -183,6 +186,7 @@ class DeviceChunk:
                 io.dst_own, io.own_pattern = own_chunk._h, int(own_pattern)
             keep += [chunk, own_chunk]
         io.dst_parts = int(parts) if dst is not None else 0
+        io.src_parts = int(src_parts) if src is not None else 0
         passes = C.c_int()
         _lib.check(_lib.load().qsim_apply_ops_io(self._h, len(nq), nq.ctypes.data_as(C.c_void_p), qs.ctypes.data_as(C.c_void_p),
                                                  mats.ctypes.data_as(C.c_void_p), C.byref(io), C.byref(passes)))
@@ -199,6 +203,16 @@ class DeviceChunk:
 
     def store_part(self, part: int) -> None:
         _lib.check(_lib.load().qsim_apply_ops_io_part(self._h, int(part)))
+
+    def source_parts(self) -> tuple:
+        """(pieces, amplitudes per piece, partial launches of the first pass) of the pending op list with a split source."""
+        n_parts, amps_, launches = C.c_int32(), C.c_uint64(), C.c_int32()
+        _lib.check(_lib.load().qsim_apply_ops_io_source_parts(self._h, C.byref(n_parts), C.byref(amps_), C.byref(launches)))
+        return n_parts.value, int(amps_.value), launches.value
+
+    def load_part(self, part: int) -> None:
+        """Piece `part` of the source of the pending op list has arrived (qsim_apply_ops_io_load)."""
+        _lib.check(_lib.load().qsim_apply_ops_io_load(self._h, int(part)))
 
     def sync(self) -> None:
         _lib.check(_lib.load().qsim_sync(self._h))
@@ -357,16 +371,22 @@ class Comm:
                                                   so.ctypes.data_as(C.c_void_p), recv._h,
                                                   ro.ctypes.data_as(C.c_void_p), int(count)))
 
-    def exchange_bg(self, peers, send: DeviceChunk, send_off, recv: DeviceChunk, recv_off, count: int) -> None:
+    def exchange_bg(self, peers, send: DeviceChunk, send_off, recv: DeviceChunk, recv_off, count: int) -> int:
         """qsim_comm_exchange_bg: the group on the communicator's transfer stream, beside later work on the chunks' stream."""
         p = np.asarray(peers, dtype=np.int32)
         so, ro = np.asarray(send_off, dtype=np.uint64), np.asarray(recv_off, dtype=np.uint64)
+        ticket = C.c_uint32()
         _lib.check(_lib.load().qsim_comm_exchange_bg(self._h, len(p), p.ctypes.data_as(C.c_void_p), send._h,
                                                      so.ctypes.data_as(C.c_void_p), recv._h,
-                                                     ro.ctypes.data_as(C.c_void_p), int(count)))
+                                                     ro.ctypes.data_as(C.c_void_p), int(count), C.byref(ticket)))
+        return ticket.value
 
     def join(self, chunk: DeviceChunk) -> None:
         _lib.check(_lib.load().qsim_comm_join(self._h, chunk._h))
+
+    def wait(self, chunk: DeviceChunk, ticket: int) -> None:
+        """The chunk's stream waits for background exchange `ticket` (qsim_comm_wait), not for later ones."""
+        _lib.check(_lib.load().qsim_comm_wait(self._h, chunk._h, int(ticket)))
 
     def relayout(self, state: DeviceChunk, buf0: DeviceChunk, buf1: DeviceChunk, local_bits, global_bits,
                  n_pieces: int = 4) -> None:

@@ -99,16 +99,21 @@ class HipShardBackend:
         self.torch.cuda.synchronize(self.device)
 
     # ---- arithmetic -----------------------------------------------------------------
-    def apply_ops(self, ops, src=None, dst=None, parts: int = 0) -> int:
+    def apply_ops(self, ops, src=None, dst=None, parts: int = 0, src_parts: int = 0) -> int:
         """HBM passes made.  src = (buffer, bits): the shard is read from that buffer in slab layout; dst = (buffer,
         bits, own_buffer, own_pattern): it is left there in slab layout (qsim_apply_ops_io: the re-layout's pack /
         unpack ride in the last / first fused pass).  parts (with dst): split form -- the slabs are stored piece by piece
-        by `store_part(j)` for every piece of `pending_parts()`."""
+        by `store_part(j)` for every piece of `pending_parts()`.  src_parts (with src): the source is still arriving in
+        pieces: nothing runs until `load_part(j)` announces them, the first pass piece by piece."""
         st = self.chunk("state")
         if src is None and dst is None:
             return st.apply_ops(ops)
         return st.apply_ops_io(ops, src=(self.chunk(src[0]), src[1]) if src else None,
-                               dst=(self.chunk(dst[0]), dst[1], self.chunk(dst[2]), dst[3]) if dst else None, parts=parts)
+                               dst=(self.chunk(dst[0]), dst[1], self.chunk(dst[2]), dst[3]) if dst else None, parts=parts,
+                               src_parts=src_parts)
+
+    def load_part(self, j: int) -> None:
+        self.chunk("state").load_part(j)
 
     def pending_parts(self) -> list:
         return self.chunk("state").pending_parts()
@@ -129,10 +134,10 @@ class HipShardBackend:
         behind everything queued on the shard's stream so far; later work on that stream does not wait for it."""
         peers = [e[0] for e in entries]
         offs = [e[1] for e in entries]
-        self.comm.exchange_bg(peers, self.chunk(send), offs, self.chunk(recv), offs, entries[0][2])
+        return self.comm.exchange_bg(peers, self.chunk(send), offs, self.chunk(recv), offs, entries[0][2])
 
-    def exchange_join(self) -> None:
-        self.comm.join(self.chunk("state"))
+    def exchange_wait(self, ticket: int) -> None:
+        self.comm.wait(self.chunk("state"), ticket)
 
     def pack_all(self, bits, dst: str, skip_pattern: int, piece: int = 0, n_pieces: int = 1) -> None:
         self.chunk("state").pack_all(bits, self.chunk(dst), skip_pattern, piece, n_pieces)
@@ -232,7 +237,8 @@ class DryBackend:
     def sync(self) -> None:
         pass
 
-    def apply_ops(self, ops, src=None, dst=None, parts: int = 0) -> int:
+    def apply_ops(self, ops, src=None, dst=None, parts: int = 0, src_parts: int = 0) -> int:
+        self._loads = len(split_pieces(self.k, len(src[1]), src_parts)) if (src is not None and src_parts) else 0
         for side in (src, dst):
             if side is not None:
                 self._check(side[1], 0, 1)
@@ -247,6 +253,10 @@ class DryBackend:
     def store_part(self, j: int) -> None:
         if not 0 <= j < len(self._parts):
             raise ValueError("bad part")
+
+    def load_part(self, j: int) -> None:
+        if not 0 <= j < self._loads:
+            raise ValueError("bad source piece")
 
     def pack_all(self, bits, dst, skip_pattern, piece=0, n_pieces=1) -> None:
         self._check(bits, piece, n_pieces)
@@ -330,6 +340,9 @@ class DistributedEngine:
         # the shard lives in a receive buffer in slab layout (None: in "state", index order).
         self.fuse_relayout = fuse_relayout
         self._state_in = None
+        # ... and, while the pieces of that re-layout may still be on the links, `_inflight` = (posted groups, timer): the
+        # next reader of the shard consumes them piece by piece (its first pass starts on the tiles whose pieces are there)
+        self._inflight = None
         # Memory per rank: the shard + the send buffer + TWO receive buffers that take turns (a pass that reads the shard
         # from one receive buffer stores its own slab into the other) = 4 shard-sized allocations with fused re-layouts
         # (64 GiB at 30 local qubits), 3 without.  Claimed here, not in the middle of a circuit.
@@ -369,8 +382,8 @@ class DistributedEngine:
             return ([], [])
         self.xgmi_bytes_sent += sum(c for _, _, c in entries) * 8
         if self.exchange_api == "cabi":
-            self.backend.exchange_bg(send, recv, [(peer, start // 2, count // 2) for peer, start, count in entries])
-            return ("cabi", [])
+            ticket = self.backend.exchange_bg(send, recv, [(peer, start // 2, count // 2) for peer, start, count in entries])
+            return ("cabi", ticket)
         st, rt = self.backend.tensor(send), self.backend.tensor(recv)
         staged, ops = [], []
         host = dist.get_backend() == "gloo"
@@ -388,7 +401,7 @@ class DistributedEngine:
         """Received data may be used by what is queued after this (RCCL: the shard's stream waits, not the host)."""
         works, staged = posted
         if works == "cabi":
-            self.backend.exchange_join()
+            self.backend.exchange_wait(staged)
             return
         for work in works:
             work.wait()
@@ -420,23 +433,51 @@ class DistributedEngine:
     def _queue_local(self, op) -> None:
         self._pending.append(op)
 
-    def _flush_local(self) -> None:
-        """Run the queued local ops (reading the shard from the receive buffer it may still live in)."""
-        if self._pending:
-            ops, self._pending = self._pending, []
-            if self._state_in is None:
-                self._passes += self.backend.apply_ops(ops) or 0
+    def _run_local(self, ops, dst=None, parts: int = 0) -> None:
+        """`ops` (may be empty) on the shard wherever it lives -- in "state", in a receive buffer in slab layout
+        (`_state_in`), or still arriving there piece by piece (`_inflight`): then the backend plans now and every piece
+        is handed over as soon as its transfer is done (torch: the shard's stream waits for that group, not the host), so
+        the first pass runs on the tiles whose pieces are there while the later pieces are on the links.  `dst` / `parts`:
+        the slab-storing end of the next re-layout."""
+        src = self._state_in
+        if src is None:
+            if dst is None:
+                if ops:
+                    self._passes += self.backend.apply_ops(ops) or 0
             else:
-                self._passes += self.backend.apply_ops(ops, src=self._state_in) or 0
-            self._state_in = None
-        elif self._state_in is not None:             # nothing to ride on: one unpack pass brings the shard home
-            buf, bits = self._state_in
-            self.backend.unpack_all(bits, buf, -1)
-            self._passes += 1
-            self._state_in = None
+                self._passes += self.backend.apply_ops(ops, dst=dst, parts=parts) or 0
+            return
+        self._state_in = None
+        if self._inflight is None:
+            self._passes += self.backend.apply_ops(ops, src=src, dst=dst, parts=parts) or 0
+            return
+        posted, timer = self._inflight
+        self._inflight = None
+        self._passes += self.backend.apply_ops(ops, src=src, dst=dst, parts=parts, src_parts=self._split_parts()) or 0
+        for j, pst in enumerate(posted):
+            self._finish(pst)
+            self.backend.load_part(j)
+        self._comm_done(timer)
+
+    def _flush_local(self) -> None:
+        """Run the queued local ops (reading the shard from the receive buffer it may still live in, or be arriving in);
+        with nothing queued a shard that is not at home is brought there (unpack pieces)."""
+        if self._pending or self._state_in is not None:
+            ops, self._pending = self._pending, []
+            self._run_local(ops)
+
+    def _drain_inflight(self) -> None:
+        """The state is about to be overwritten: wait for transfers that still write into the exchange buffers."""
+        if self._inflight is not None:
+            posted, timer = self._inflight
+            self._inflight = None
+            for pst in posted:
+                self._finish(pst)
+            self._comm_done(timer)
 
     # ---- state ---------------------------------------------------------------------------
     def init_zero_state(self) -> None:
+        self._drain_inflight()
         self._pending = []
         self._state_in = None
         self.backend.init_zero(self.rank == 0)
@@ -608,20 +649,18 @@ class DistributedEngine:
             # the send side.  The cut depends only on (k, m, pieces): all ranks post the same messages in the same order
             # whatever their own pass plans look like (a rank whose last pass holds a piece bit as a tile bit has all its
             # pieces ready at once: it overlaps less, it does not post differently).  The first pass AFTER the exchange
-            # still waits for every piece (its tiles read all slabs).
+            # takes the pieces over as they arrive (`_inflight`, qsim_ops_io::src_parts): it runs on the tiles whose
+            # pieces are there -- when the piece bits are no tile bits of it -- while the later pieces are on the links.
             rname = "buf2" if (self._state_in is not None and self._state_in[0] == "buf1") else "buf1"
             ops, self._pending = self._pending, []
-            self._passes += self.backend.apply_ops(ops, src=self._state_in, dst=("buf0", loc, rname, mine),
-                                                   parts=self._split_parts(pieces)) or 0
-            self._state_in = None
+            self._run_local(ops, dst=("buf0", loc, rname, mine), parts=self._split_parts())
             timer = self._comm_timer(send)
             posted = []
             for j, (off, cnt) in enumerate(self.backend.pending_parts()):
                 self.backend.store_part(j)
                 posted.append(self._post("buf0", rname, [(peer, d * slab + 2 * off, 2 * cnt) for d, peer in peers]))
-            for pst in posted:
-                self._finish(pst)
-            self._comm_done(timer)
+            # nobody waits here: the next reader of the shard takes the pieces over as they arrive (_run_local)
+            self._inflight = (posted, timer)
             self._state_in = (rname, list(loc))
             return
         self._flush_local()
@@ -638,12 +677,10 @@ class DistributedEngine:
             self.backend.unpack_all(loc, "buf1", mine, s, pieces)
         self._comm_done(timer)
 
-    def _split_parts(self, pieces: int) -> int:
-        """qsim_ops_io::dst_parts for a fused re-layout: the configured pieces; negative (no 2^20-amplitude floor on a
-        run) when the engine was built with a lower floor (tests on small shards)."""
-        want = max(pieces, 2) if self.relayout_pieces > 1 else 1
-        if want == 1:
-            return -1                                        # split form with one piece
+    def _split_parts(self) -> int:
+        """qsim_ops_io::dst_parts / src_parts of a fused re-layout: the configured pieces (the library keeps a piece >=
+        2^20 amplitudes); negative (no floor) when the engine was built with a lower floor (tests on small shards)."""
+        want = self.relayout_pieces
         return want if self.min_piece_qubits >= 20 else -want
 
     def _relayout_pieces(self, slab_qubits: int) -> int:

@@ -73,10 +73,33 @@ class CpuShardBackend:
     def sync(self) -> None:
         pass
 
-    def apply_ops(self, ops, src=None, dst=None, parts: int = 0) -> None:
+    def apply_ops(self, ops, src=None, dst=None, parts: int = 0, src_parts: int = 0) -> None:
         """src / dst: the fused re-layout ends of qsim_apply_ops_io (runner/distributed.py), restated with the slab
         helpers below: read the shard from a receive buffer in slab layout / leave it in slab layout for the exchange
-        (own slab in the receive buffer)."""
+        (own slab in the receive buffer).  src_parts: the source is still arriving: nothing happens until `load_part`
+        has taken every piece over -- each piece is COPIED out of the receive buffer when it is announced, so a piece
+        announced before its transfer is done shows up as a wrong result."""
+        if src is not None and src_parts:
+            from quantum_simulations_amd.runner.distributed import split_pieces
+            self._deferred = (list(ops), src, dst, parts, split_pieces(self.k, len(src[1]), src_parts),
+                              np.full(1 << self.k, np.nan + 1j * np.nan), set())
+            return
+        self._apply_now(ops, src, dst, parts)
+
+    def load_part(self, j: int) -> None:
+        ops, src, dst, parts, pieces, staged, seen = self._deferred
+        assert 0 <= j < len(pieces) and j not in seen
+        seen.add(j)
+        off, cnt = pieces[j]
+        slab = 1 << (self.k - len(src[1]))
+        for d in range(1 << len(src[1])):
+            staged[d * slab + off:d * slab + off + cnt] = self._c(src[0])[d * slab + off:d * slab + off + cnt]
+        if len(seen) == len(pieces):
+            self._c(src[0])[:] = staged              # (what the pieces brought, piece by piece)
+            self._deferred = None
+            self._apply_now(ops, src, dst, parts)
+
+    def _apply_now(self, ops, src, dst, parts) -> None:
         if src is not None:
             self.unpack_all(src[1], src[0], -1)
         orc.apply_ops(self._c("state"), ops)

@@ -207,3 +207,78 @@ def test_split_form_stores_the_slabs_piece_by_piece(k):
         state.store_part(j)
     for c in (state, buf0, buf1, ref0, ref1):
         c.close()
+
+
+@pytest.mark.parametrize("k", [7, 14, 17, 21])
+def test_split_source_consumes_the_pieces_as_they_arrive(k):
+    """qsim_ops_io::src_parts (the receive side of a fused re-layout): the call plans and launches nothing; every
+    `load_part(j)` may only touch source pieces that have been announced.  Here a piece's data is written into the source
+    buffer (NaN before) right before it is announced and everything queued is drained before the next one, so a launch
+    that read an unannounced piece would leave NaNs.  First pass with the top bits free (partial launches) and taken by
+    the tile (whole, with the last piece), the unpack fallback (slab bit inside a line), chunks too small for tiles, an
+    empty op list, a destination in one launch and in pieces, a single pass that is also the slab-storing one."""
+    from quantum_simulations_amd.kernel.device import DeviceChunk
+    from quantum_simulations_amd.runner.distributed import split_pieces
+    rng = np.random.default_rng(1300 + k)
+    state, src, dst, keep = (DeviceChunk.empty(k) for _ in range(4))
+    n = 1 << k
+    idx = np.arange(n)
+    launches_seen = set()
+    for trial in range(12):
+        m = int(rng.integers(1, min(3, k - 4) + 1))
+        bits = [int(b) for b in rng.choice(np.arange(3, k), size=m, replace=False)]
+        if trial == 7:
+            bits[0] = 2                                       # slab bit inside a 128-byte line: unpack pieces
+        ops = _random_ops(k, 40, 7700 + 13 * k + trial) if trial != 8 else []
+        top = [b for b in range(k - 1, -1, -1) if b not in bits][:2]
+        if trial in (2, 5):                                   # the piece bits are tile bits of the first pass
+            ops = [([q], orc.gate_matrix("H")) for q in top] + ops
+        if trial in (3, 6, 9):                                # nothing touches them at all
+            ops = [(qs, U) for qs, U in ops if not set(qs) & set(top)]
+        if trial == 10:                                       # ONE pass that is also the slab-storing pass
+            ops = [([5], orc.gate_matrix("H")), ([5, 6], orc.gate_matrix("CNOT"))]
+        with_dst = trial in (4, 6, 10, 11)
+        psi0 = _rand_state(k, 7800 + trial)
+        want = psi0.copy()
+        orc.apply_ops(want, ops)
+        slab = n >> m
+        pat = sum(((idx >> b) & 1) << i for i, b in enumerate(bits))
+        packed = np.concatenate([psi0[pat == d] for d in range(1 << m)])
+        src.upload(np.full(n, np.nan + 1j * np.nan))
+        state.upload(np.full(n, np.nan + 1j * np.nan))
+        bits2 = [int(b) for b in rng.choice(np.arange(3, k), size=m, replace=False)]
+        own = int(rng.integers(0, 1 << m))
+        dst.init_zero(False)
+        keep.init_zero(False)
+        passes = state.apply_ops_io(ops, src=(src, bits), dst=(dst, bits2, keep, own) if with_dst else None,
+                                    parts=-2 if trial in (6, 10) else 0, src_parts=-4)
+        assert passes >= 1
+        pieces = split_pieces(k, m, -4)
+        n_parts, amps_, launches = state.source_parts()
+        assert n_parts == len(pieces) and amps_ == pieces[0][1]
+        launches_seen.add(launches)
+        with pytest.raises(ValueError, match="pending"):
+            state.apply_ops(ops or [([3], orc.gate_matrix("H"))])
+        for j in (int(x) for x in rng.permutation(n_parts)):
+            off, cnt = pieces[j]
+            for d in range(1 << m):
+                src.upload(packed[d * slab + off:d * slab + off + cnt], d * slab + off)
+            state.load_part(j)
+            state.sync()
+        if with_dst:
+            if trial in (6, 10):
+                for j in range(len(state.pending_parts())):
+                    state.store_part(j)
+            g0, g1 = dst.download(), keep.download()
+            pat2 = sum(((idx >> b) & 1) << i for i, b in enumerate(bits2))
+            for d in range(1 << m):
+                got = (g1 if d == own else g0)[d * slab:(d + 1) * slab]
+                np.testing.assert_allclose(got, want[pat2 == d], rtol=0, atol=1e-11, err_msg=f"k={k} trial={trial} slab {d}")
+        else:
+            np.testing.assert_allclose(state.download(), want, rtol=0, atol=1e-11, err_msg=f"k={k} trial={trial} bits={bits}")
+        with pytest.raises(ValueError):
+            state.load_part(0)                                # nothing pending any more
+    if k >= 14:
+        assert 4 in launches_seen and 0 in launches_seen, launches_seen
+    for c in (state, src, dst, keep):
+        c.close()
