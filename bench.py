@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--depth", type=int, default=40)
     ap.add_argument("--mode", choices=["fused", "per-gate"], default="fused",
                     help="fused: planner passes (batch_levels + tile fusion); per-gate: one launch per gate")
+    ap.add_argument("--layout", choices=["auto", "identity"], default="auto",
+                    help="N = 1: auto = the engine chooses which index bit a qubit lives on (tile-pattern model); identity = bit q")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-sweep", action="store_true", help="skip the per-target sweeps (config 3)")
@@ -191,13 +193,13 @@ def pmc_traffic_per_launch(kernel_prefix: str, local_qubits: int = 28):
     return best
 
 
-def fused_run(n: int, depth: int, steps: int, warmup: int, device: int) -> dict:
+def fused_run(n: int, depth: int, steps: int, warmup: int, device: int, layout: str = "auto") -> dict:
     """The fused workload at another size on a fresh state (N = 1: the 30-qubit random 1q+CX circuit, the largest
     single-GPU configuration of BASELINE.json's list that bench.py times): passes, ms per pass by HIP events,
     roofline fraction of the bytes the launches move, gate-applications/s by the host clock."""
     from quantum_simulations_amd.circuits import random_1q_cx_circuit
     from quantum_simulations_amd.runner.engine import SingleGpuEngine
-    eng = SingleGpuEngine(n, device=device, mode="fused")
+    eng = SingleGpuEngine(n, device=device, mode="fused", layout=layout)
     circuit = random_1q_cx_circuit(n, depth=depth)
     n_gates = len(circuit["gates"])
     eng.init_zero_state()
@@ -223,7 +225,8 @@ def fused_run(n: int, depth: int, steps: int, warmup: int, device: int) -> dict:
             "hbm_passes_per_step": passes, "kernel": dom["kernel"], "launches": dom["launches"],
             "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4),
             "bytes_per_launch": dom["hbm_bytes"] / dom["launches"],
-            "achieved_GBps": round(moved, 1), "frac": round(moved / HBM_PEAK_GBS, 4), "norm2_after": norm2}
+            "achieved_GBps": round(moved, 1), "frac": round(moved / HBM_PEAK_GBS, 4), "norm2_after": norm2,
+            "qubit_layout": "identity" if getattr(plan, "l2p", None) is None else plan.l2p}
 
 
 # ---------------------------------------------------------------------------------- N = 1
@@ -235,7 +238,7 @@ def run_single(args, k: int) -> tuple[dict, list[str]]:
     n = k
     circuit = random_1q_cx_circuit(n, depth=args.depth)
     n_gates = len(circuit["gates"])
-    engine = make_engine(n, 1, 0, int(os.environ.get("LOCAL_RANK", "0")), mode=args.mode)
+    engine = make_engine(n, 1, 0, int(os.environ.get("LOCAL_RANK", "0")), mode=args.mode, layout=args.layout)
     engine.init_zero_state()
     plan = engine.plan(circuit, repeats=args.warmup + args.steps)
     for _ in range(args.warmup):
@@ -296,7 +299,12 @@ def run_single(args, k: int) -> tuple[dict, list[str]]:
         "config": {"workload": f"{n}-qubit random 1q+CX circuit depth {args.depth} (seed 20260228), "
                                f"{n_gates} gates, complex128, {k} local qubits per GPU",
                    "n_qubits": n, "local_qubits": k, "gates_per_step": n_gates, "mode": args.mode,
-                   "hbm_passes_per_step": passes},
+                   "hbm_passes_per_step": passes,
+                   # which index bit a qubit lives on: chosen per plan from a measured model of the tiles' DRAM pattern
+                   # (runner/tile_layout.py); the passes are the same, the state is held in that layout
+                   "qubit_layout": ("identity" if getattr(plan, "l2p", None) is None else
+                                    {"logical_to_index_bit": plan.l2p, "tile_cost_model_ms_identity_vs_chosen":
+                                     [round(x, 3) for x in (plan.model_ms or (0, 0))]})},
         "timed_seconds": round(dt, 4),
         "amplitude_updates_per_s": n_gates * args.steps * float(1 << n) / dt,
         "sustained": sustained,
@@ -309,7 +317,7 @@ def run_single(args, k: int) -> tuple[dict, list[str]]:
         # the same workload family at the largest single-GPU size of BASELINE.json's list (16 GiB state): ~2 s of GPU
         # time, so the 30-qubit figure of the fused pass is timed by the driver's run and not only by profiles/
         out["fused%d" % args.fused_qubits] = fused_run(args.fused_qubits, args.depth, steps=5, warmup=2,
-                                                        device=int(os.environ.get("LOCAL_RANK", "0")))
+                                                        device=int(os.environ.get("LOCAL_RANK", "0")), layout=args.layout)
         if abs(out["fused%d" % args.fused_qubits]["norm2_after"] - 1.0) > NORM_TOL:
             invalid.append(f"fused{args.fused_qubits}: norm check failed")
     if not args.no_sweep:

@@ -86,6 +86,12 @@ int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* q
 int qsim_apply_ops_unfused(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits,
                            const double* mats);
 int qsim_last_pass_count(const qsim_chunk* c);
+/* qsim_apply_ops with the high tile bits of the first n_tiles fused passes named by the caller (bit b of tile_masks[p]: index
+ * bit b is a tile bit of pass p) instead of searched for: a host that planned the list once (qsim_plan_ops: every pass image
+ * carries its tile bits) and then moved its qubits to other index bits -- a layout chosen for the DRAM pattern of the tiles,
+ * runner/engine.py -- gets the same passes on the new bits.  A mask that holds no op is ignored (the search takes over). */
+int qsim_apply_ops_tiled(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,
+                         int n_tiles, const uint64_t* tile_masks);
 
 /* ---- op list with a re-layout fused into its ends ------------------------------------------------
  * Multi-GPU re-layouts (the staging SWAP lists of wenbo_engine/circuit/staging.py:136-152, merged into one
@@ -138,6 +144,8 @@ int qsim_split_piece_count(int n_local_qubits, int m, int dst_parts);   /* the p
 #define QSIM_PASS_IMAGE_BYTES 4096
 int qsim_plan_ops(int n_local_qubits, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,
                   void* out, uint64_t out_capacity_bytes, int32_t* n_passes);
+int qsim_plan_ops_tiled(int n_local_qubits, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,
+                        int n_tiles, const uint64_t* tile_masks, void* out, uint64_t out_capacity_bytes, int32_t* n_passes);
 
 /* ---- partner-chunk butterflies (cpu_nonlocal.*) ----------------------------------- */
 int qsim_apply_1q_pair(qsim_chunk* c0, qsim_chunk* c1, const double U[8]);

@@ -57,6 +57,8 @@ SIGNATURES = {
     "qsim_apply_ops": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "qsim_apply_ops_unfused": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "qsim_plan_ops": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, C.c_uint64, _P]),
+    "qsim_plan_ops_tiled": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_uint64, _P]),
+    "qsim_apply_ops_tiled": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P]),
     "qsim_last_pass_count": (C.c_int, [_P]),
     "qsim_apply_ops_io": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.POINTER(C.c_int)]),
     "qsim_apply_ops_io_part": (C.c_int, [_P, C.c_int]),

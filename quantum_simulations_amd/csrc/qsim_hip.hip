@@ -358,12 +358,46 @@ int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* q
   return rc;
 }
 
+// qsim_apply_ops with the high tile bits of the first n_tiles passes named by the caller (bit b of tile_masks[p]: index bit b
+// is a tile bit of pass p): the pass builder takes them instead of searching; a mask that holds no op is ignored.
+int qsim_apply_ops_tiled(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,
+                         int n_tiles, const uint64_t* tile_masks) {
+  int rc = validate_ops(c, n_ops, nq, qubits, mats);
+  if (rc) return rc;
+  if (n_tiles < 0 || (n_tiles && !tile_masks)) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_tiled: bad tile list");
+  if (parts_pending(c)) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_tiled: slab pieces of a split qsim_apply_ops_io call are pending on this chunk");
+  if (n_ops < 2 || c->k < kTileMinChunk || c->k > kTileMaxQubits) {
+    c->last_passes = n_ops;
+    return qsim_apply_ops_unfused(c, n_ops, nq, qubits, mats);
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  std::vector<FusedOp> ops;
+  ops.reserve(n_ops);
+  for (int i = 0; i < n_ops; ++i) {
+    FusedOp o;
+    if (classify_op(nq[i], qubits + 2 * i, mats + 32 * (size_t)i, &o)) ops.push_back(o);
+  }
+  int passes = 0;
+  const TileHint hint = {tile_masks, n_tiles};
+  rc = run_fused(c, ops, &passes, nullptr, n_ops, nq, qubits, mats, nullptr, n_tiles ? &hint : nullptr);
+  c->last_passes = passes;
+  return rc;
+}
+
 int qsim_last_pass_count(const qsim_chunk* c) { return c ? c->last_passes : -1; }
 
 static_assert(sizeof(TileArgs) == QSIM_PASS_IMAGE_BYTES, "pass image = the kernel-argument block of k_tile");
 
+int qsim_plan_ops_tiled(int n_local_qubits, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,
+                        int n_tiles, const uint64_t* tile_masks, void* out, uint64_t out_capacity_bytes, int32_t* n_passes);
 int qsim_plan_ops(int n_local_qubits, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,
                   void* out, uint64_t out_capacity_bytes, int32_t* n_passes) {
+  return qsim_plan_ops_tiled(n_local_qubits, n_ops, nq, qubits, mats, 0, nullptr, out, out_capacity_bytes, n_passes);
+}
+
+int qsim_plan_ops_tiled(int n_local_qubits, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,
+                        int n_tiles, const uint64_t* tile_masks, void* out, uint64_t out_capacity_bytes, int32_t* n_passes) {
+  if (n_tiles < 0 || (n_tiles && !tile_masks)) return fail(QSIM_ERR_INVALID, "qsim_plan_ops_tiled: bad tile list");
   if (!n_passes) return fail(QSIM_ERR_INVALID, "qsim_plan_ops: n_passes is null");
   if (n_local_qubits < kTileMinChunk || n_local_qubits > kTileMaxQubits)
     return fail(QSIM_ERR_INVALID, "qsim_plan_ops: fused passes need %d..%d local qubits", kTileMinChunk, kTileMaxQubits);
@@ -382,6 +416,7 @@ int qsim_plan_ops(int n_local_qubits, int n_ops, const int32_t* nq, const int32_
   int passes = 0;
   char* dst = (char*)out;
   uint64_t used = 0;
+  const TileHint hint = {tile_masks, n_tiles};
   int rc = plan_fused(n_local_qubits, ops, &passes, [&](TileArgs& a, int T, double, bool, bool) {
     if (dst) {
       if (used + sizeof(TileArgs) > out_capacity_bytes) return fail(QSIM_ERR_INVALID, "qsim_plan_ops: output buffer too small");
@@ -389,7 +424,7 @@ int qsim_plan_ops(int n_local_qubits, int n_ops, const int32_t* nq, const int32_
     }
     used += sizeof(TileArgs);
     return (int)QSIM_OK;
-  });
+  }, n_tiles ? &hint : nullptr);
   *n_passes = passes;
   return rc;
 }

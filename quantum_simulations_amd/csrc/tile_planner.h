@@ -805,8 +805,13 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
 // AFTER it could hold (one pass fewer on the bench circuits).  QSIM_PLAN_LOOKAHEAD = 0 / 1 / 2 forces.
 // `sink(args, T, algorithmic_bytes, first, last)` receives every planned pass (first / last of the op list): the
 // launcher on the device path, a serialiser in qsim_plan_ops (the planner itself never touches the GPU).
+// `hint` (qsim_apply_ops_tiled): the caller names the high tile bits of the first passes itself -- a host that has planned
+// the list once and moved its qubits to other index bits (a layout chosen for the memory pattern of the tiles:
+// runner/engine.py) gets the SAME passes on the new bits instead of whatever the search finds there.  A hint that holds no
+// op (or too many bits) is ignored and the search takes over for that pass.
+struct TileHint { const uint64_t* masks; int n; };
 template <class Sink>
-static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, Sink&& sink) {
+static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, Sink&& sink, const TileHint* hint = nullptr) {
   const Tuning& tune = tuning();
   std::vector<FusedOp> ops = ops_in;
   if (tune.tile_commute_fuse == 1 || tune.tile_commute_fuse == 4) commute_fuse_1q(&ops, false);
@@ -964,8 +969,15 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
   while (remaining) {
     while (first < n_ops && done[first]) ++first;
     scan_window = remaining > 4 * (size_t)tune.plan_scan_window ? std::max(1, tune.plan_scan_window * 2 / 3) : tune.plan_scan_window;
+    u64 best_mask = 0;
+    bool hinted = false;
+    if (hint && *n_passes < hint->n) {
+      const u64 m = hint->masks[*n_passes] & all_qubits & ~((1ull << low) - 1);
+      if (m && __builtin_popcountll(m) <= cap && holds(m, nullptr) > 0) { best_mask = m; hinted = true; }
+    }
+    if (!hinted) {
     candidates(&cands, 6, 2, prev_mask);
-    u64 best_mask = cands[0];
+    best_mask = cands[0];
     int best_score = -(1 << 20);
     for (size_t ci = 0; ci < cands.size(); ++ci) {
       trial.clear();
@@ -986,6 +998,7 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
       }
       score = keyed(score, cands[ci]);
       if (score > best_score) { best_score = score; best_mask = cands[ci]; }
+    }
     }
     std::vector<int> high;                      // chosen high bits
     for (int b = low; b < k; ++b) if ((best_mask >> b) & 1) high.push_back(b);
@@ -1253,18 +1266,21 @@ static u64 fnv1a(const unsigned char* p, size_t n, u64 h = 1469598103934665603ul
 // in) but not launched; the caller launches them when the source is complete.
 static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_passes, FusedIo* io = nullptr,
                      int n_ops = 0, const int32_t* nq = nullptr, const int32_t* qubits = nullptr, const double* mats = nullptr,
-                     std::vector<CachedPass>* defer = nullptr) {
+                     std::vector<CachedPass>* defer = nullptr, const TileHint* hint = nullptr) {
   // key of the call (only when the caller handed the raw op list over)
   std::vector<unsigned char> key;
   u64 hash = 0;
-  const size_t key_bytes = (size_t)n_ops * (sizeof(int32_t) * 3 + sizeof(double) * 32);
-  const bool cacheable = nq && qubits && mats && n_ops > 0 && key_bytes <= kPlanCacheMaxKeyBytes && tuning().debug_stats == 0;
+  const size_t hint_bytes = hint ? sizeof(uint64_t) * (size_t)hint->n : 0;
+  const size_t key_bytes = (size_t)n_ops * (sizeof(int32_t) * 3 + sizeof(double) * 32) + hint_bytes;
+  const bool cacheable = nq && qubits && mats && n_ops > 0 && key_bytes <= kPlanCacheMaxKeyBytes && tuning().debug_stats == 0 &&
+                         tuning().debug_skip_gates == 0;     // (probe passes take their tile bits from the environment at plan time)
   if (cacheable) {
     key.resize(key_bytes);
     unsigned char* w = key.data();
     std::memcpy(w, nq, sizeof(int32_t) * (size_t)n_ops); w += sizeof(int32_t) * (size_t)n_ops;
     std::memcpy(w, qubits, sizeof(int32_t) * 2 * (size_t)n_ops); w += sizeof(int32_t) * 2 * (size_t)n_ops;
-    std::memcpy(w, mats, sizeof(double) * 32 * (size_t)n_ops);
+    std::memcpy(w, mats, sizeof(double) * 32 * (size_t)n_ops); w += sizeof(double) * 32 * (size_t)n_ops;
+    if (hint_bytes) std::memcpy(w, hint->masks, hint_bytes);
     hash = fnv1a(key.data(), key.size(), 1469598103934665603ull ^ (u64)c->k);
     std::vector<CachedPass> hit;
     {
@@ -1299,7 +1315,7 @@ static int run_fused(qsim_chunk* c, const std::vector<FusedOp>& ops, int* n_pass
       return (int)QSIM_OK;
     }
     return launch_planned(c, a, T, alg_bytes, first, last, io);
-  });
+  }, hint);
   if (rc == QSIM_OK && cacheable && !made.empty()) {
     std::lock_guard<std::mutex> lock(g_plan_cache_mu);
     g_plan_cache.emplace_front();

@@ -139,6 +139,16 @@ class DeviceChunk:
         m, p = _mat_ptr(U, 4)
         _lib.check(_lib.load().qsim_apply_2q(self._h, int(qa), int(qb), p))
 
+    def apply_ops_tiled(self, ops, tile_masks) -> int:
+        """`apply_ops` (fused) with the high tile bits of the first passes given (qsim_apply_ops_tiled): `tile_masks` =
+        uint64 array, bit b of entry p = index bit b is a tile bit of pass p.  Returns the HBM round trips."""
+        nq, qs, mats = ops if (isinstance(ops, tuple) and len(ops) == 3 and isinstance(ops[0], np.ndarray)) else pack_ops(ops)
+        tm = np.ascontiguousarray(tile_masks, dtype=np.uint64)
+        lib = _lib.load()
+        _lib.check(lib.qsim_apply_ops_tiled(self._h, len(nq), nq.ctypes.data_as(C.c_void_p), qs.ctypes.data_as(C.c_void_p),
+                                            mats.ctypes.data_as(C.c_void_p), len(tm), tm.ctypes.data_as(C.c_void_p)))
+        return lib.qsim_last_pass_count(self._h)
+
     def apply_ops(self, ops, fused: bool = True) -> int:
         """One pass: every (qubits, U) of `ops` in one C call.  `fused` groups them into LDS-tile
         launches (order kept for ops sharing a qubit); returns the number of HBM round trips.

@@ -852,7 +852,8 @@ class DistributedEngine:
         try:
             one.init_zero_state()
             one.execute(one.plan(cd))
-            return [[one.state.fingerprint(self.n, 0, None, seed, m, v) for m, v in sel] for sel in selector_sets]
+            # (the one-GPU engine holds its state in a layout of its own choice: undone by the fingerprint itself)
+            return [[one.state.fingerprint(self.n, 0, one.l2p, seed, m, v) for m, v in sel] for sel in selector_sets]
         finally:
             one.close()
 

@@ -24,46 +24,122 @@ def gate_ops(cd: dict) -> list:
     return [(g["qubits"], gate_table.gate_matrix(g["gate"], g["params"])) for g in cd["gates"]]
 
 
+class GpuPlan(list):
+    """A single-GPU plan: the list of batches ((nq, qubits, mats) packed for ONE C call each, in PHYSICAL index bits) plus
+    `tiles` (per batch the high tile bits of its fused passes as uint64 masks, or None: let the library search) and `l2p`
+    (the qubit layout the batches were written for: logical qubit q on index bit l2p[q]; None = identity)."""
+    tiles: list
+    l2p: list | None = None
+    model_ms: tuple | None = None        # (identity, chosen) totals of the tile-cost model over the passes, when a layout was chosen
+
+
 class SingleGpuEngine:
-    """The whole 2^n state on one MI355X (n <= 33 fits 288 GB)."""
+    """The whole 2^n state on one MI355X (n <= 33 fits 288 GB).
+
+    layout = "auto" (fused mode, states of >= 26 qubits): `plan` plans the circuit once on the CPU (`qsim_plan_ops`),
+    chooses which index bit every logical qubit lives on so that the passes' tiles fall on index-bit sets with a good DRAM
+    pattern (runner/tile_layout.py: a model fitted to measured passes), and hands the SAME passes to the library on the
+    new bits (`qsim_apply_ops_tiled`).  The state is then held in that layout -- the reference's `log_to_phys` notion
+    (staging.py:587-658) -- and `state_vector()` / `logical_index()` undo it.  layout = "identity": index bit = qubit."""
 
     world = 1
     rank = 0
+    LAYOUT_MIN_QUBITS = 26
 
-    def __init__(self, n_qubits: int, device: int = 0, mode: str = "fused"):
+    def __init__(self, n_qubits: int, device: int = 0, mode: str = "fused", layout: str = "auto"):
+        if layout not in ("auto", "identity"):
+            raise ValueError("layout must be 'auto' or 'identity'")
         self.n = n_qubits
         self.mode = mode
+        self.layout_mode = layout
         self.state = DeviceChunk.empty(n_qubits, device)
+        self.l2p: list | None = None        # layout of the state right now (None = identity)
+        self._zero = False                  # the state is |0..0>: the same vector in every layout
 
     # ---- state ---------------------------------------------------------------------
     def init_zero_state(self) -> None:
         self.state.init_zero(True)
+        self.l2p, self._zero = None, True
 
     def init_random_state(self, seed: int) -> None:
         self.state.init_random(seed)
+        self.l2p, self._zero = None, False
 
     def norm2(self) -> float:
         return self.state.norm2()
 
     def state_vector(self) -> np.ndarray:
-        return self.state.download()
+        """The state in LOGICAL qubit order (the layout undone on the host: small n)."""
+        psi = self.state.download()
+        if self.l2p is None:
+            return psi
+        from quantum_simulations_amd.circuit.staging import permute_state
+        return permute_state(psi, self.l2p)
+
+    def logical_index(self, offset: int, count: int) -> np.ndarray:
+        """Logical amplitude indices of the physical range [offset, offset + count) of the state in its current layout."""
+        x = offset + np.arange(count, dtype=np.int64)
+        if self.l2p is None:
+            return x
+        y = np.zeros_like(x)
+        for q, p in enumerate(self.l2p):
+            y |= ((x >> p) & 1) << q
+        return y
 
     # ---- planning / execution --------------------------------------------------------
-    def plan(self, circuit_dict: dict, repeats: int = 1) -> list:
-        """Plan = list of passes, each a list of (qubits, U) handed to ONE C call (the same
-        plan serves every repeat: the single-GPU layout never changes)."""
+    def plan(self, circuit_dict: dict, repeats: int = 1) -> GpuPlan:
+        """Plan = list of batches, each handed to ONE C call (the same plan serves every repeat: the layout of a
+        single-GPU run is chosen once per plan and never changes)."""
         cd = validate_circuit_dict(circuit_dict)
         if cd["number_of_qubits"] != self.n:
             raise ValueError(f"circuit has {cd['number_of_qubits']} qubits, engine has {self.n}")
         from quantum_simulations_amd.kernel.device import pack_ops
         if self.mode == "per-gate":
-            return [pack_ops(gate_ops(cd))]
-        return [pack_ops(p["local_ops"]) for p in batch_levels(levelize(cd), self.n)]
+            plan = GpuPlan([pack_ops(gate_ops(cd))])
+            plan.tiles = [None]
+            return plan
+        batches = [p["local_ops"] for p in batch_levels(levelize(cd), self.n)]
+        if self.layout_mode != "auto" or self.n < self.LAYOUT_MIN_QUBITS:
+            plan = GpuPlan([pack_ops(ops) for ops in batches])
+            plan.tiles = [None] * len(batches)
+            return plan
+        from quantum_simulations_amd.runner import tile_layout
+        masks = [_planned_tile_masks(self.n, ops) for ops in batches]          # the passes, as sets of logical qubits
+        tiles = [[b for b in range(tile_layout.LOW, self.n) if (int(m) >> b) & 1] for ms in masks for m in ms]
+        l2p, cost0, cost1 = tile_layout.choose_layout(tiles, self.n)
+        if not cost1 < cost0:
+            l2p = list(range(self.n))
+        plan = GpuPlan([pack_ops([([l2p[q] for q in qs], U) for qs, U in ops]) for ops in batches])
+        plan.tiles = [np.array([sum(1 << l2p[b] for b in range(self.n) if (int(m) >> b) & 1) for m in ms], dtype=np.uint64)
+                      for ms in masks]
+        plan.l2p = None if l2p == list(range(self.n)) else l2p
+        plan.model_ms = (cost0, cost1)
+        return plan
 
-    def execute(self, plan: list) -> None:
+    def _adopt_layout(self, l2p) -> None:
+        """Bring the state into the layout a plan was written for."""
+        if l2p == self.l2p or (l2p is None and self.l2p == list(range(self.n))):
+            return
+        if self._zero:                      # |0..0> looks the same in every layout
+            self.l2p = l2p
+            return
+        # a non-trivial state: move the qubits with SWAP gates (fused passes; rare -- a new plan on a used state)
+        SW = gate_table.SWAP()
+        swaps = [([a, b], SW) for a, b in layout_swaps(self.l2p, l2p, self.n)]
+        if swaps:
+            self.state.apply_ops(swaps)
+        self.l2p = l2p
+
+    def execute(self, plan) -> None:
+        self._adopt_layout(getattr(plan, "l2p", None))
+        self._zero = False
         self.last_passes = 0
-        for ops in plan:
-            self.last_passes += self.state.apply_ops(ops, fused=self.mode != "per-gate")
+        tiles = getattr(plan, "tiles", None) or [None] * len(plan)
+        for ops, masks in zip(plan, tiles):
+            if masks is not None and self.mode != "per-gate":
+                self.last_passes += self.state.apply_ops_tiled(ops, masks)
+            else:
+                self.last_passes += self.state.apply_ops(ops, fused=self.mode != "per-gate")
 
     def passes_per_step(self, plan: list) -> int:
         """HBM round trips of the last executed step (fused tile launches or single gates)."""
@@ -88,6 +164,8 @@ class SingleGpuEngine:
         H(q) 32 * 2^n for every q; secondary rows T(q), CNOT(q, q+1), CNOT(0, q) at 16 * 2^n."""
         dev = self.state if n == self.n else DeviceChunk.empty(n, self.state.device)
         dev.init_random(30)
+        if dev is self.state:
+            self.l2p, self._zero = None, False
         H, T, CX = gate_table.H(), gate_table.T(), gate_table.CNOT()
         N = 1 << n
 
@@ -172,9 +250,49 @@ class SingleGpuEngine:
         self.state.close()
 
 
+def layout_swaps(cur, want, n: int) -> list:
+    """Index-bit pairs whose SWAPs, applied in order, take a state from layout `cur` to layout `want` (logical qubit q on
+    index bit layout[q]; None = identity): at most n - 1 of them."""
+    cur = list(cur) if cur is not None else list(range(n))
+    want = list(want) if want is not None else list(range(n))
+    at = {p: q for q, p in enumerate(cur)}              # index bit -> the logical qubit on it
+    swaps = []
+    for q in range(n):
+        a, b = cur[q], want[q]
+        if a != b:
+            other = at[b]                               # the qubit sitting where q has to go
+            swaps.append((a, b))
+            at[a], at[b] = other, q
+            cur[other], cur[q] = a, b
+    return swaps
+
+
+def _planned_tile_masks(n: int, ops) -> np.ndarray:
+    """The high tile bits of the fused passes the library plans for `ops` on n qubits, one uint64 mask per pass
+    (qsim_plan_ops: the host planner without a device; offset of `h` in a pass image: csrc/tile_kernel.h TileArgs)."""
+    import ctypes as C
+
+    from quantum_simulations_amd import _lib
+    from quantum_simulations_amd.kernel.device import pack_ops
+    nq, qubits, mats = pack_ops(ops)
+    lib = _lib.load()
+    count = C.c_int32()
+    if len(nq) < 2:
+        return np.zeros(0, dtype=np.uint64)
+    args = (n, len(nq), nq.ctypes.data_as(C.c_void_p), qubits.ctypes.data_as(C.c_void_p), mats.ctypes.data_as(C.c_void_p))
+    _lib.check(lib.qsim_plan_ops(*args, None, 0, C.byref(count)))
+    images = np.zeros((count.value, 4096), dtype=np.uint8)
+    _lib.check(lib.qsim_plan_ops(*args, images.ctypes.data_as(C.c_void_p), images.nbytes, C.byref(count)))
+    out = np.zeros(count.value, dtype=np.uint64)
+    for p in range(count.value):
+        T = int(images[p, 12:16].view("<i4")[0])
+        out[p] = sum(1 << int(b) for b in images[p, 16:16 + T - 3])
+    return out
+
+
 def make_engine(n_qubits: int, world: int = 1, rank: int = 0, local_rank: int = 0,
                 mode: str = "fused", **kw):
     if world == 1:                      # (rehearsal / exchange only mean something with more than one rank)
-        return SingleGpuEngine(n_qubits, device=local_rank, mode=mode)
+        return SingleGpuEngine(n_qubits, device=local_rank, mode=mode, layout=kw.get("layout", "auto"))
     from quantum_simulations_amd.runner.distributed import DistributedEngine
     return DistributedEngine(n_qubits, world, rank, local_rank, mode=mode, **kw)

@@ -1,0 +1,110 @@
+"""Qubit layout chosen for the DRAM pattern of the fused passes' tiles (round 4).
+
+What a fused pass costs at 28-30 qubits is decided by WHICH index bits its tile holds (1.32-2.3 ms
+for the same data volume; the gate-less time of a tile-bit set predicts the time of the pass WITH its gates at r = 0.83).
+The pass builder cannot pay for a better pattern with extra passes (measured), but the engine is free to decide which
+index bit a logical qubit lives on: the passes -- their tiles as SETS OF QUBITS -- stay exactly the same and only the
+index bits under them change.  This module holds
+
+  * a cost model of a tile-bit set: constant + per-bit terms + pair terms, a ridge fit to a few thousand gate-less passes
+    over random tile-bit sets measured on MI355X (`tools/fit_tile_cost_model.py` <- `tools/tile_bits_sample.py`; the
+    coefficients ship as `tile_cost_model.json`);
+  * `choose_layout(tiles, n)`: simulated annealing over the assignment qubit -> index bit (bits 0-2, the 128-byte line,
+    stay) minimising the model's total over the circuit's passes -- a second or so on the host, outside any timed region.
+
+The reference has the same notion for another purpose: `atlas_stages` returns `log_to_phys` and `permute_state` undoes it
+(wenbo_engine/circuit/staging.py:587-658); `SingleGpuEngine` tracks its layout the same way.
+"""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+
+import numpy as np
+
+LOW = 3                                              # bits 0..2 = one 128-byte line: always tile bits, never moved
+_MODEL_PATH = Path(__file__).resolve().parent / "tile_cost_model.json"
+_models: dict | None = None
+
+
+def _load_models() -> dict:
+    global _models
+    if _models is None:
+        doc = json.loads(_MODEL_PATH.read_text())
+        _models = {int(k): {"c0": m["c0"], "bit": np.asarray(m["bit"], dtype=np.float64),
+                            "pair": np.asarray(m["pair"], dtype=np.float64), "top": int(m["top"])}
+                   for k, m in doc["models"].items()}
+    return _models
+
+
+def model_for(n: int) -> dict:
+    """The fit made at the state size nearest to n (an index bit is an address bit whatever n is; bits above the
+    fitted range are priced like the highest fitted one)."""
+    models = _load_models()
+    key = min(models, key=lambda k: (abs(k - n), k))
+    return models[key]
+
+
+def tile_cost(model: dict, bits) -> float:
+    """Predicted milliseconds (at the model's own state size) of a pass whose tile holds the index bits `bits` (>= 3)."""
+    idx = sorted(min(int(b), model["top"]) - LOW for b in bits)
+    c = model["c0"] + float(model["bit"][idx].sum())
+    pair = model["pair"]
+    for i, a in enumerate(idx):
+        for b in idx[i + 1:]:
+            if a != b:
+                c += float(pair[a, b])
+    return c
+
+
+def choose_layout(tiles: list, n: int, seed: int = 1, sweeps: int = 30) -> tuple:
+    """tiles: the high tile bits (logical qubits >= 3) of every pass of the circuit.  Returns (l2p, cost_identity,
+    cost_chosen): logical qubit q lives on index bit l2p[q]."""
+    model = model_for(n)
+    pos = list(range(LOW, n))
+    if len(pos) < 2 or not tiles:
+        return list(range(n)), 0.0, 0.0
+    top = model["top"]
+    bitw, pairw = model["bit"], model["pair"]
+    tiles = [[int(q) for q in t if q >= LOW] for t in tiles]
+    member = {q: [ti for ti, t in enumerate(tiles) if q in t] for q in pos}
+    l2p = {q: q for q in pos}
+
+    sym = pairw + pairw.T                            # (zero diagonal: two clamped bits on one index cost nothing extra)
+
+    def cost_of(ti: int) -> float:
+        idx = [min(l2p[q], top) - LOW for q in tiles[ti]]
+        return float(bitw[idx].sum()) + 0.5 * float(sym[np.ix_(idx, idx)].sum())
+    costs = [cost_of(ti) for ti in range(len(tiles))]
+    identity = sum(costs)
+    cur = best = identity
+    best_l2p = dict(l2p)
+    rng = np.random.default_rng(seed)
+    steps = sweeps * len(pos) * len(pos) // 2
+    T0 = max(1e-3, 0.03 * identity / max(1, len(tiles)))
+    picks_a = rng.integers(0, len(pos), size=steps)
+    picks_b = rng.integers(0, len(pos) - 1, size=steps)
+    uniform = rng.random(steps)
+    for it in range(steps):
+        ia, ib = int(picks_a[it]), int(picks_b[it])
+        a, b = pos[ia], pos[ib if ib < ia else ib + 1]
+        touched = set(member[a]) | set(member[b])
+        if not touched:
+            continue
+        l2p[a], l2p[b] = l2p[b], l2p[a]
+        new = {ti: cost_of(ti) for ti in touched}
+        delta = sum(new.values()) - sum(costs[ti] for ti in touched)
+        T = T0 * (1.0 - it / steps) + 1e-4
+        if delta < 0 or uniform[it] < np.exp(-delta / T):
+            for ti, c in new.items():
+                costs[ti] = c
+            cur += delta
+            if cur < best - 1e-12:
+                best, best_l2p = cur, dict(l2p)
+        else:
+            l2p[a], l2p[b] = l2p[b], l2p[a]
+    out = list(range(n))
+    for q, p in best_l2p.items():
+        out[q] = p
+    c0 = model["c0"] * len(tiles)
+    return out, identity + c0, best + c0
