@@ -52,8 +52,9 @@ def parse_args():
     ap.add_argument("--depth", type=int, default=40)
     ap.add_argument("--mode", choices=["fused", "per-gate"], default="fused",
                     help="fused: planner passes (batch_levels + tile fusion); per-gate: one launch per gate")
-    ap.add_argument("--layout", choices=["auto", "identity"], default="auto",
-                    help="N = 1: auto = the engine chooses which index bit a qubit lives on (tile-pattern model); identity = bit q")
+    ap.add_argument("--layout", choices=["auto", "search", "identity"], default="auto",
+                    help="N = 1: auto / search = the engine chooses which index bit a qubit lives on (line-bit qubits for the "
+                         "pass count, the rest by the tile-pattern model); identity = bit q")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-sweep", action="store_true", help="skip the per-target sweeps (config 3)")
@@ -226,7 +227,8 @@ def fused_run(n: int, depth: int, steps: int, warmup: int, device: int, layout: 
             "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4),
             "bytes_per_launch": dom["hbm_bytes"] / dom["launches"],
             "achieved_GBps": round(moved, 1), "frac": round(moved / HBM_PEAK_GBS, 4), "norm2_after": norm2,
-            "qubit_layout": "identity" if getattr(plan, "l2p", None) is None else plan.l2p}
+            "qubit_layout": "identity" if getattr(plan, "l2p", None) is None else
+                            {"logical_to_index_bit": plan.l2p, **getattr(plan, "layout_info", {})}}
 
 
 # ---------------------------------------------------------------------------------- N = 1
@@ -303,8 +305,7 @@ def run_single(args, k: int) -> tuple[dict, list[str]]:
                    # which index bit a qubit lives on: chosen per plan from a measured model of the tiles' DRAM pattern
                    # (runner/tile_layout.py); the passes are the same, the state is held in that layout
                    "qubit_layout": ("identity" if getattr(plan, "l2p", None) is None else
-                                    {"logical_to_index_bit": plan.l2p, "tile_cost_model_ms_identity_vs_chosen":
-                                     [round(x, 3) for x in (plan.model_ms or (0, 0))]})},
+                                    {"logical_to_index_bit": plan.l2p, **getattr(plan, "layout_info", {})})},
         "timed_seconds": round(dt, 4),
         "amplitude_updates_per_s": n_gates * args.steps * float(1 << n) / dt,
         "sustained": sustained,

@@ -147,6 +147,19 @@ int qsim_plan_ops(int n_local_qubits, int n_ops, const int32_t* nq, const int32_
 int qsim_plan_ops_tiled(int n_local_qubits, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,
                         int n_tiles, const uint64_t* tile_masks, void* out, uint64_t out_capacity_bytes, int32_t* n_passes);
 
+/* Pass counts of ONE op list under n_layouts qubit layouts (layouts[l * n_local_qubits + q] = index bit of logical qubit q),
+ * planned in parallel on n_threads host threads, no device: the pass builder's result depends on which qubits live on the
+ * three line bits (they belong to every tile), so a host that is free to choose the layout tries several. */
+int qsim_plan_count_layouts(int n_local_qubits, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,
+                            int n_layouts, const int32_t* layouts, int32_t* n_passes, int n_threads);
+
+/* The qubit layout search of runner/tile_layout.py as host code: simulated annealing over the assignment qubit -> index bit
+ * (bits 0..2 stay) minimising sum over the passes of the caller's cost model of their tile-bit sets (see the .hip for the
+ * model's form).  tile_masks[p] = high tile bits of pass p as logical qubits; out_l2p[q] = index bit for qubit q. */
+int qsim_choose_layout(int n_local_qubits, int n_tiles, const uint64_t* tile_masks, int top_bit, const double* bit_cost,
+                       const double* pair_cost, uint64_t seed, int sweeps, int32_t* out_l2p, double* cost_identity,
+                       double* cost_chosen);
+
 /* ---- partner-chunk butterflies (cpu_nonlocal.*) ----------------------------------- */
 int qsim_apply_1q_pair(qsim_chunk* c0, qsim_chunk* c1, const double U[8]);
 int qsim_apply_2q_pair_qa_local(qsim_chunk* c0, qsim_chunk* c1, int qa, const double U[32]);

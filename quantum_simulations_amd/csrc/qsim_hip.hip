@@ -32,6 +32,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -427,6 +428,131 @@ int qsim_plan_ops_tiled(int n_local_qubits, int n_ops, const int32_t* nq, const 
   }, n_tiles ? &hint : nullptr);
   *n_passes = passes;
   return rc;
+}
+
+// Pass counts of ONE op list under several qubit layouts (layouts[l * n_local_qubits + q] = the index bit of logical qubit q
+// in layout l), planned in parallel on the host: the greedy pass builder's result depends on which three qubits live on the
+// line bits (they belong to every tile) -- 17 to 20 passes for the 28-qubit bench circuit -- so an engine that is free to
+// choose the layout (runner/engine.py) tries a few dozen and keeps the cheapest.  No device involved.
+int qsim_plan_count_layouts(int n_local_qubits, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,
+                            int n_layouts, const int32_t* layouts, int32_t* n_passes, int n_threads) {
+  if (!n_passes || n_layouts < 0 || (n_layouts && !layouts)) return fail(QSIM_ERR_INVALID, "qsim_plan_count_layouts: bad arguments");
+  if (n_local_qubits < kTileMinChunk || n_local_qubits > kTileMaxQubits)
+    return fail(QSIM_ERR_INVALID, "qsim_plan_count_layouts: fused passes need %d..%d local qubits", kTileMinChunk, kTileMaxQubits);
+  if (n_ops < 0 || (n_ops && (!nq || !qubits || !mats))) return fail(QSIM_ERR_INVALID, "bad op list");
+  for (int i = 0; i < n_ops; ++i) {
+    if (nq[i] != 1 && nq[i] != 2) return fail(QSIM_ERR_INVALID, "op %d: arity %d", i, nq[i]);
+    for (int j = 0; j < nq[i]; ++j)
+      if (qubits[2 * i + j] < 0 || qubits[2 * i + j] >= n_local_qubits) return fail(QSIM_ERR_NONLOCAL, "qubit %d >= log2(chunk_size)=%d: non-local gate requires layout/collect step", qubits[2 * i + j], n_local_qubits);
+    if (nq[i] == 2 && qubits[2 * i] == qubits[2 * i + 1]) return fail(QSIM_ERR_INVALID, "op %d: repeated qubit", i);
+  }
+  for (int l = 0; l < n_layouts; ++l) {
+    u64 seen = 0;
+    for (int q = 0; q < n_local_qubits; ++q) {
+      const int b = layouts[(size_t)l * n_local_qubits + q];
+      if (b < 0 || b >= n_local_qubits || ((seen >> b) & 1)) return fail(QSIM_ERR_INVALID, "qsim_plan_count_layouts: layout %d is not a permutation", l);
+      seen |= 1ull << b;
+    }
+  }
+  (void)tuning();                                          // (initialised before the threads start)
+  std::atomic<int> next{0}, bad{0};
+  auto work = [&]() {
+    std::vector<FusedOp> ops;
+    for (;;) {
+      const int l = next.fetch_add(1);
+      if (l >= n_layouts) return;
+      const int32_t* lay = layouts + (size_t)l * n_local_qubits;
+      ops.clear();
+      for (int i = 0; i < n_ops; ++i) {
+        const int32_t q[2] = {lay[qubits[2 * i]], nq[i] == 2 ? lay[qubits[2 * i + 1]] : -1};
+        FusedOp o;
+        if (classify_op(nq[i], q, mats + 32 * (size_t)i, &o)) ops.push_back(o);
+      }
+      int passes = 0;
+      const int rc = plan_fused(n_local_qubits, ops, &passes, [](TileArgs&, int, double, bool, bool) { return (int)QSIM_OK; });
+      if (rc) bad.store(1);
+      n_passes[l] = rc ? -1 : passes;
+    }
+  };
+  const int nt = std::max(1, std::min(n_threads > 0 ? n_threads : 1, std::min(n_layouts, 64)));
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+  work();
+  for (std::thread& t : pool) t.join();
+  if (bad.load()) return fail(QSIM_ERR_INVALID, "qsim_plan_count_layouts: a layout could not be planned");
+  return QSIM_OK;
+}
+
+// Which index bit should every qubit live on so that the tiles of the given passes fall on index-bit sets with a good DRAM
+// pattern?  Simulated annealing over the assignment (bits 0..2, the 128-byte line, stay) under the caller's cost model of
+// a tile-bit set: c0 + sum_b bit_cost[b - 3] + sum_{a < b} pair_cost[(a - 3) * nb + (b - 3)], nb = top_bit - 2, bits above
+// top_bit priced like top_bit (runner/tile_layout.py holds the coefficients: ridge fits to measured passes).  tile_masks[p] =
+// the high tile bits of pass p as LOGICAL qubits; out_l2p[q] = the index bit chosen for qubit q.  Host only.
+int qsim_choose_layout(int n_local_qubits, int n_tiles, const uint64_t* tile_masks, int top_bit, const double* bit_cost,
+                       const double* pair_cost, uint64_t seed, int sweeps, int32_t* out_l2p, double* cost_identity, double* cost_chosen) {
+  const int n = n_local_qubits, low = kTileLow;
+  if (n < low + 2 || n > 62 || n_tiles < 0 || (n_tiles && !tile_masks) || !bit_cost || !pair_cost || !out_l2p || top_bit < low || top_bit > 62 || sweeps < 1)
+    return fail(QSIM_ERR_INVALID, "qsim_choose_layout: bad arguments");
+  const int nb = top_bit - low + 1;
+  std::vector<std::vector<int>> tiles((size_t)n_tiles);
+  std::vector<std::vector<int>> member((size_t)n);
+  for (int t = 0; t < n_tiles; ++t)
+    for (int q = low; q < n; ++q)
+      if ((tile_masks[t] >> q) & 1) { tiles[(size_t)t].push_back(q); member[(size_t)q].push_back(t); }
+  std::vector<double> sym((size_t)nb * nb, 0.0);
+  for (int a = 0; a < nb; ++a)
+    for (int b = a + 1; b < nb; ++b) sym[(size_t)a * nb + b] = sym[(size_t)b * nb + a] = pair_cost[(size_t)a * nb + b];
+  std::vector<int> l2p((size_t)n);
+  for (int q = 0; q < n; ++q) l2p[(size_t)q] = q;
+  auto cost_of = [&](int t) {
+    int idx[64], m = 0;
+    for (int q : tiles[(size_t)t]) idx[m++] = std::min(l2p[(size_t)q], top_bit) - low;
+    double c = 0;
+    for (int i = 0; i < m; ++i) {
+      c += bit_cost[idx[i]];
+      for (int j = i + 1; j < m; ++j) c += sym[(size_t)idx[i] * nb + idx[j]];
+    }
+    return c;
+  };
+  std::vector<double> costs((size_t)n_tiles);
+  double cur = 0;
+  for (int t = 0; t < n_tiles; ++t) cur += (costs[(size_t)t] = cost_of(t));
+  const double identity = cur;
+  double best = cur;
+  std::vector<int> best_l2p = l2p;
+  u64 rs = seed * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull;
+  auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
+  const int np_ = n - low;
+  const long steps = (long)sweeps * np_ * np_ / 2;
+  const double T0 = std::max(1e-3, 0.03 * identity / std::max(1, n_tiles));
+  std::vector<int> touched;
+  std::vector<double> fresh;
+  for (long it = 0; it < steps && n_tiles > 0; ++it) {
+    const int a = low + (int)(rnd() % (u64)np_);
+    int b = low + (int)(rnd() % (u64)(np_ - 1));
+    if (b >= a) ++b;
+    touched.clear();
+    for (int t : member[(size_t)a]) touched.push_back(t);
+    for (int t : member[(size_t)b]) if (std::find(touched.begin(), touched.end(), t) == touched.end()) touched.push_back(t);
+    if (touched.empty()) continue;
+    std::swap(l2p[(size_t)a], l2p[(size_t)b]);
+    fresh.clear();
+    double delta = 0;
+    for (int t : touched) { fresh.push_back(cost_of(t)); delta += fresh.back() - costs[(size_t)t]; }
+    const double T = T0 * (1.0 - (double)it / (double)steps) + 1e-4;
+    const double u = (double)(rnd() >> 11) * 0x1p-53;
+    if (delta < 0 || u < std::exp(-delta / T)) {
+      for (size_t i = 0; i < touched.size(); ++i) costs[(size_t)touched[i]] = fresh[i];
+      cur += delta;
+      if (cur < best - 1e-12) { best = cur; best_l2p = l2p; }
+    } else {
+      std::swap(l2p[(size_t)a], l2p[(size_t)b]);
+    }
+  }
+  for (int q = 0; q < n; ++q) out_l2p[q] = best_l2p[(size_t)q];
+  if (cost_identity) *cost_identity = identity;
+  if (cost_chosen) *cost_chosen = best;
+  return QSIM_OK;
 }
 
 int qsim_apply_1q_pair(qsim_chunk* c0, qsim_chunk* c1, const double U[8]) {

@@ -36,19 +36,27 @@ class GpuPlan(list):
 class SingleGpuEngine:
     """The whole 2^n state on one MI355X (n <= 33 fits 288 GB).
 
-    layout = "auto" (fused mode, states of >= 26 qubits): `plan` plans the circuit once on the CPU (`qsim_plan_ops`),
-    chooses which index bit every logical qubit lives on so that the passes' tiles fall on index-bit sets with a good DRAM
-    pattern (runner/tile_layout.py: a model fitted to measured passes), and hands the SAME passes to the library on the
-    new bits (`qsim_apply_ops_tiled`).  The state is then held in that layout -- the reference's `log_to_phys` notion
-    (staging.py:587-658) -- and `state_vector()` / `logical_index()` undo it.  layout = "identity": index bit = qubit."""
+    layout = "auto" (fused mode, states of >= 26 qubits, plans made for >= 8 executions) / "search" (always): `plan`
+    decides which index bit every logical qubit lives on --
+      * the three qubits on the LINE bits 0..2 belong to every tile, so which three they are changes how many passes the
+        greedy pass builder needs (17-20 for the 28-qubit bench circuit): a few dozen random choices are planned on the
+        host in parallel (`qsim_plan_count_layouts`) and the cheapest kept;
+      * the other qubits are placed so that the passes' tiles fall on index-bit sets with a good DRAM pattern
+        (runner/tile_layout.py: a cost model fitted to measured passes, annealed by `qsim_choose_layout`) --
+    and hands the SAME passes to the library on the new bits (`qsim_apply_ops_tiled`).  The state is then held in that
+    layout -- the reference's `log_to_phys` notion (staging.py:587-658) -- and `state_vector()` / `logical_index()` undo
+    it.  About a second of host work per plan, outside every timed region: worth it for plans that run many times.
+    layout = "identity": index bit = qubit, no search."""
 
     world = 1
     rank = 0
     LAYOUT_MIN_QUBITS = 26
+    LAYOUT_MIN_REPEATS = 8         # layout = "auto": plans for fewer executions are not worth a second of search
+    LAYOUT_CANDIDATES = 128        # random choices of the three line-bit qubits that are planned and counted
 
     def __init__(self, n_qubits: int, device: int = 0, mode: str = "fused", layout: str = "auto"):
-        if layout not in ("auto", "identity"):
-            raise ValueError("layout must be 'auto' or 'identity'")
+        if layout not in ("auto", "search", "identity"):
+            raise ValueError("layout must be 'auto', 'search' or 'identity'")
         self.n = n_qubits
         self.mode = mode
         self.layout_mode = layout
@@ -99,21 +107,19 @@ class SingleGpuEngine:
             plan.tiles = [None]
             return plan
         batches = [p["local_ops"] for p in batch_levels(levelize(cd), self.n)]
-        if self.layout_mode != "auto" or self.n < self.LAYOUT_MIN_QUBITS:
+        search = self.layout_mode == "search" or (self.layout_mode == "auto" and repeats >= self.LAYOUT_MIN_REPEATS)
+        if not search or self.n < self.LAYOUT_MIN_QUBITS:
             plan = GpuPlan([pack_ops(ops) for ops in batches])
             plan.tiles = [None] * len(batches)
             return plan
-        from quantum_simulations_amd.runner import tile_layout
-        masks = [_planned_tile_masks(self.n, ops) for ops in batches]          # the passes, as sets of logical qubits
-        tiles = [[b for b in range(tile_layout.LOW, self.n) if (int(m) >> b) & 1] for ms in masks for m in ms]
-        l2p, cost0, cost1 = tile_layout.choose_layout(tiles, self.n)
-        if not cost1 < cost0:
-            l2p = list(range(self.n))
+        import time
+        t0 = time.perf_counter()
+        l2p, masks, info = choose_plan_layout(self.n, batches, self.LAYOUT_CANDIDATES)
         plan = GpuPlan([pack_ops([([l2p[q] for q in qs], U) for qs, U in ops]) for ops in batches])
-        plan.tiles = [np.array([sum(1 << l2p[b] for b in range(self.n) if (int(m) >> b) & 1) for m in ms], dtype=np.uint64)
-                      for ms in masks]
+        plan.tiles = masks
         plan.l2p = None if l2p == list(range(self.n)) else l2p
-        plan.model_ms = (cost0, cost1)
+        plan.model_ms = info["model_ms"]
+        plan.layout_info = dict(info, seconds=round(time.perf_counter() - t0, 3))
         return plan
 
     def _adopt_layout(self, l2p) -> None:
@@ -265,6 +271,66 @@ def layout_swaps(cur, want, n: int) -> list:
             at[a], at[b] = other, q
             cur[other], cur[q] = a, b
     return swaps
+
+
+def _count_passes(n: int, batches, layouts: np.ndarray, threads: int) -> np.ndarray:
+    """Fused passes of the batches under each layout (rows of `layouts`: qubit -> index bit), planned on the host."""
+    import ctypes as C
+
+    from quantum_simulations_amd import _lib
+    from quantum_simulations_amd.kernel.device import pack_ops
+    lib = _lib.load()
+    total = np.zeros(len(layouts), dtype=np.int64)
+    lay = np.ascontiguousarray(layouts, dtype=np.int32)
+    for ops in batches:
+        nq, qubits, mats = pack_ops(ops)
+        if len(nq) < 2:
+            total += len(nq)
+            continue
+        out = np.zeros(len(lay), dtype=np.int32)
+        _lib.check(lib.qsim_plan_count_layouts(n, len(nq), nq.ctypes.data_as(C.c_void_p), qubits.ctypes.data_as(C.c_void_p),
+                                               mats.ctypes.data_as(C.c_void_p), len(lay), lay.ctypes.data_as(C.c_void_p),
+                                               out.ctypes.data_as(C.c_void_p), threads))
+        total += out
+    return total
+
+
+def choose_plan_layout(n: int, batches, n_candidates: int = 128, seed: int = 20260504) -> tuple:
+    """(l2p, tile masks per batch on the chosen index bits, info) for the op lists `batches` (logical qubits): the line-bit
+    qubits that need the fewest passes among `n_candidates` random choices (the identity included), then the other
+    qubits placed by the tile-cost model (runner/tile_layout.py).  Host only."""
+    import os
+
+    from quantum_simulations_amd.runner import tile_layout
+    rng = np.random.default_rng(seed)
+    layouts = np.tile(np.arange(n, dtype=np.int32), (n_candidates + 1, 1))
+    for row in layouts[1:]:
+        for bit, q in enumerate(int(x) for x in rng.choice(n, size=3, replace=False)):
+            j = int(np.flatnonzero(row == bit)[0])          # the qubit on `bit` trades places with q
+            row[j], row[q] = row[q], bit
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    counts = _count_passes(n, batches, layouts, max(1, min(16, threads)))
+    best = int(counts.min())
+    finalists = [int(i) for i in np.flatnonzero(counts == best)][:4]       # (the identity first when it ties)
+    chosen = None
+    for f in finalists:
+        first = [int(x) for x in layouts[f]]
+        moved = [[([first[q] for q in qs], U) for qs, U in ops] for ops in batches]
+        masks = [_planned_tile_masks(n, ops) for ops in moved]
+        tiles = [[b for b in range(tile_layout.LOW, n) if (int(m) >> b) & 1] for ms in masks for m in ms]
+        cand = min((tile_layout.choose_layout(tiles, n, seed=s) for s in range(1, 9)), key=lambda r: r[2])
+        if chosen is None or cand[2] < chosen[1][2]:
+            chosen = (first, cand, masks)
+    first, (second, cost0, cost1), masks = chosen
+    l2p = [second[first[q]] for q in range(n)]
+    final_masks = [np.array([sum(1 << second[b] for b in range(n) if (int(m) >> b) & 1) for m in ms], dtype=np.uint64) for ms in masks]
+    info = {"passes_identity": int(counts[0]), "passes_chosen": best, "candidates": n_candidates + 1,
+            "candidates_by_passes": {int(c): int((counts == c).sum()) for c in np.unique(counts)},
+            "model_ms": (round(cost0, 3), round(cost1, 3))}
+    return l2p, final_masks, info
 
 
 def _planned_tile_masks(n: int, ops) -> np.ndarray:

@@ -57,54 +57,23 @@ def tile_cost(model: dict, bits) -> float:
     return c
 
 
-def choose_layout(tiles: list, n: int, seed: int = 1, sweeps: int = 30) -> tuple:
+def choose_layout(tiles: list, n: int, seed: int = 1, sweeps: int = 200) -> tuple:
     """tiles: the high tile bits (logical qubits >= 3) of every pass of the circuit.  Returns (l2p, cost_identity,
-    cost_chosen): logical qubit q lives on index bit l2p[q]."""
+    cost_chosen) in the model's milliseconds: logical qubit q lives on index bit l2p[q].  The annealing itself is host
+    code of the library (qsim_choose_layout: ~10 ms for the bench circuits)."""
+    import ctypes as C
+
+    from quantum_simulations_amd import _lib
     model = model_for(n)
-    pos = list(range(LOW, n))
-    if len(pos) < 2 or not tiles:
+    if n < LOW + 2 or not tiles:
         return list(range(n)), 0.0, 0.0
-    top = model["top"]
-    bitw, pairw = model["bit"], model["pair"]
-    tiles = [[int(q) for q in t if q >= LOW] for t in tiles]
-    member = {q: [ti for ti, t in enumerate(tiles) if q in t] for q in pos}
-    l2p = {q: q for q in pos}
-
-    sym = pairw + pairw.T                            # (zero diagonal: two clamped bits on one index cost nothing extra)
-
-    def cost_of(ti: int) -> float:
-        idx = [min(l2p[q], top) - LOW for q in tiles[ti]]
-        return float(bitw[idx].sum()) + 0.5 * float(sym[np.ix_(idx, idx)].sum())
-    costs = [cost_of(ti) for ti in range(len(tiles))]
-    identity = sum(costs)
-    cur = best = identity
-    best_l2p = dict(l2p)
-    rng = np.random.default_rng(seed)
-    steps = sweeps * len(pos) * len(pos) // 2
-    T0 = max(1e-3, 0.03 * identity / max(1, len(tiles)))
-    picks_a = rng.integers(0, len(pos), size=steps)
-    picks_b = rng.integers(0, len(pos) - 1, size=steps)
-    uniform = rng.random(steps)
-    for it in range(steps):
-        ia, ib = int(picks_a[it]), int(picks_b[it])
-        a, b = pos[ia], pos[ib if ib < ia else ib + 1]
-        touched = set(member[a]) | set(member[b])
-        if not touched:
-            continue
-        l2p[a], l2p[b] = l2p[b], l2p[a]
-        new = {ti: cost_of(ti) for ti in touched}
-        delta = sum(new.values()) - sum(costs[ti] for ti in touched)
-        T = T0 * (1.0 - it / steps) + 1e-4
-        if delta < 0 or uniform[it] < np.exp(-delta / T):
-            for ti, c in new.items():
-                costs[ti] = c
-            cur += delta
-            if cur < best - 1e-12:
-                best, best_l2p = cur, dict(l2p)
-        else:
-            l2p[a], l2p[b] = l2p[b], l2p[a]
-    out = list(range(n))
-    for q, p in best_l2p.items():
-        out[q] = p
-    c0 = model["c0"] * len(tiles)
-    return out, identity + c0, best + c0
+    masks = np.array([sum(1 << int(q) for q in t if q >= LOW) for t in tiles], dtype=np.uint64)
+    bit = np.ascontiguousarray(model["bit"], dtype=np.float64)
+    pair = np.ascontiguousarray(model["pair"], dtype=np.float64)
+    out = np.zeros(n, dtype=np.int32)
+    c0, c1 = C.c_double(), C.c_double()
+    _lib.check(_lib.load().qsim_choose_layout(n, len(masks), masks.ctypes.data_as(C.c_void_p), model["top"],
+                                              bit.ctypes.data_as(C.c_void_p), pair.ctypes.data_as(C.c_void_p), seed, sweeps,
+                                              out.ctypes.data_as(C.c_void_p), C.byref(c0), C.byref(c1)))
+    base = model["c0"] * len(tiles)
+    return [int(x) for x in out], c0.value + base, c1.value + base

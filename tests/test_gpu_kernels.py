@@ -266,9 +266,12 @@ def test_config2_full_circuit_every_amplitude_vs_c_oracle_28q(hip):
     from quantum_simulations_amd.runner.engine import SingleGpuEngine
     n = 28
     cd = validate_circuit_dict(random_1q_cx_circuit(n, depth=40))
-    eng = SingleGpuEngine(n)
+    eng = SingleGpuEngine(n, layout="search")            # line-bit qubits for the pass count + tile-pattern layout
     eng.init_zero_state()
-    eng.execute(eng.plan(cd))
+    plan = eng.plan(cd)
+    assert plan.layout_info["passes_chosen"] <= plan.layout_info["passes_identity"] == 18
+    eng.execute(plan)
+    assert eng.last_passes == plan.layout_info["passes_chosen"]              # the library took the named tiles
     assert abs(eng.norm2() - 1.0) < 1e-10
     try:
         cores = len(os.sched_getaffinity(0))
