@@ -200,7 +200,8 @@ def fused_run(n: int, depth: int, steps: int, warmup: int, device: int, layout: 
     roofline fraction of the bytes the launches move, gate-applications/s by the host clock."""
     from quantum_simulations_amd.circuits import random_1q_cx_circuit
     from quantum_simulations_amd.runner.engine import SingleGpuEngine
-    eng = SingleGpuEngine(n, device=device, mode="fused", layout=layout)
+    # (a few steps of a run that would repeat the plan many times: the layout search is made as for such a run)
+    eng = SingleGpuEngine(n, device=device, mode="fused", layout="search" if layout == "auto" else layout)
     circuit = random_1q_cx_circuit(n, depth=depth)
     n_gates = len(circuit["gates"])
     eng.init_zero_state()

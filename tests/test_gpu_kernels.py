@@ -281,7 +281,7 @@ def test_config2_full_circuit_every_amplitude_vs_c_oracle_28q(hip):
     want = c_oracle.simulate(cd)
     worst = 0.0
     step = 1 << 24
-    assert eng.l2p is not None and sorted(eng.l2p) == list(range(n)) and eng.l2p[:3] == [0, 1, 2]    # a layout was chosen
+    assert eng.l2p is not None and sorted(eng.l2p) == list(range(n))                                 # a layout was chosen
     for off in range(0, 1 << n, step):
         got = eng.state.download(off, step)
         worst = max(worst, float(np.max(np.abs(got - want[eng.logical_index(off, step)]))))         # (the engine's layout undone)

@@ -95,3 +95,61 @@ def test_named_tiles_give_the_same_passes_on_other_index_bits():
     _lib.check(lib.qsim_plan_ops_tiled(n, len(nq), nq.ctypes.data_as(C.c_void_p), qubits.ctypes.data_as(C.c_void_p),
                                        mats.ctypes.data_as(C.c_void_p), 1, junk.ctypes.data_as(C.c_void_p), None, 0, C.byref(count)))
     assert count.value >= 1
+
+
+def test_choose_plan_layout_names_the_planned_passes_and_never_needs_more_of_them():
+    """runner/engine.choose_plan_layout on the CPU: the chosen layout is a permutation, needs no more passes than the
+    identity (the identity is one of the candidates), and the tile masks it names ARE the passes the library plans for the
+    relabelled op list (qsim_plan_ops_tiled takes them: same count, same tiles)."""
+    import ctypes as C
+
+    from quantum_simulations_amd import _lib
+    from quantum_simulations_amd.circuit.fusion import batch_levels
+    from quantum_simulations_amd.circuit.io import levelize, validate_circuit_dict
+    from quantum_simulations_amd.circuits import random_1q_cx_circuit
+    from quantum_simulations_amd.kernel.device import pack_ops
+    from quantum_simulations_amd.runner.engine import choose_plan_layout
+    from tests import tile_interpreter as ti
+    n = 26
+    cd = validate_circuit_dict(random_1q_cx_circuit(n, depth=12, seed=7))
+    batches = [p["local_ops"] for p in batch_levels(levelize(cd), n)]
+    l2p, masks, info = choose_plan_layout(n, batches, n_candidates=24)
+    assert sorted(l2p) == list(range(n))
+    assert info["passes_chosen"] <= info["passes_identity"] and info["candidates"] == 25
+    assert sum(info["candidates_by_passes"].values()) == 25 and info["model_ms"][1] <= info["model_ms"][0] + 1e-9
+    assert sum(len(m) for m in masks) == info["passes_chosen"]
+    lib = _lib.load()
+    for ops, ms in zip(batches, masks):
+        nq, qubits, mats = pack_ops([([l2p[q] for q in qs], U) for qs, U in ops])
+        count = C.c_int32()
+        args = (n, len(nq), nq.ctypes.data_as(C.c_void_p), qubits.ctypes.data_as(C.c_void_p), mats.ctypes.data_as(C.c_void_p),
+                len(ms), ms.ctypes.data_as(C.c_void_p))
+        _lib.check(lib.qsim_plan_ops_tiled(*args, None, 0, C.byref(count)))
+        assert count.value == len(ms)
+        images = np.zeros(count.value, dtype=ti._IMAGE)
+        _lib.check(lib.qsim_plan_ops_tiled(*args, images.ctypes.data_as(C.c_void_p), images.nbytes, C.byref(count)))
+        for img, want in zip(images, ms):
+            assert sum(1 << int(b) for b in img["h"][:int(img["T"]) - 3]) == int(want)
+
+
+def test_plan_count_layouts_matches_single_plans_and_rejects_bad_layouts():
+    import ctypes as C
+
+    from quantum_simulations_amd import _lib
+    from quantum_simulations_amd.kernel.device import pack_ops
+    from quantum_simulations_amd.runner.engine import _count_passes
+    from tests import tile_interpreter as ti
+    from tests.test_gpu_kernels import _random_ops
+    n = 15
+    ops = _random_ops(n, 200, 99)
+    rng = np.random.default_rng(2)
+    layouts = np.array([np.arange(n)] + [rng.permutation(n) for _ in range(9)], dtype=np.int32)
+    counts = _count_passes(n, [ops], layouts, 4)
+    for lay, c in zip(layouts, counts):
+        assert c == len(ti.plan(n, [([int(lay[q]) for q in qs], U) for qs, U in ops]))
+    nq, qubits, mats = pack_ops(ops)
+    bad = np.zeros((1, n), dtype=np.int32)
+    out = np.zeros(1, dtype=np.int32)
+    rc = _lib.load().qsim_plan_count_layouts(n, len(nq), nq.ctypes.data_as(C.c_void_p), qubits.ctypes.data_as(C.c_void_p),
+                                             mats.ctypes.data_as(C.c_void_p), 1, bad.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), 2)
+    assert rc == -1
