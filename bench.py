@@ -241,7 +241,10 @@ def run_single(args, k: int) -> tuple[dict, list[str]]:
     n = k
     circuit = random_1q_cx_circuit(n, depth=args.depth)
     n_gates = len(circuit["gates"])
-    engine = make_engine(n, 1, 0, int(os.environ.get("LOCAL_RANK", "0")), mode=args.mode, layout=args.layout)
+    # (the timed steps stand for a run that repeats its plan many times: the layout search is made as for such a run,
+    # whatever --steps / --warmup are)
+    engine = make_engine(n, 1, 0, int(os.environ.get("LOCAL_RANK", "0")), mode=args.mode,
+                         layout="search" if args.layout == "auto" else args.layout)
     engine.init_zero_state()
     plan = engine.plan(circuit, repeats=args.warmup + args.steps)
     for _ in range(args.warmup):
