@@ -201,7 +201,8 @@ def fused_run(n: int, depth: int, steps: int, warmup: int, device: int, layout: 
     from quantum_simulations_amd.circuits import random_1q_cx_circuit
     from quantum_simulations_amd.runner.engine import SingleGpuEngine
     # (a few steps of a run that would repeat the plan many times: the layout search is made as for such a run)
-    eng = SingleGpuEngine(n, device=device, mode="fused", layout="search" if layout == "auto" else layout)
+    eng = SingleGpuEngine(n, device=device, mode="fused", layout="search" if layout == "auto" else layout,
+                          tune_on_device=layout == "auto")
     circuit = random_1q_cx_circuit(n, depth=depth)
     n_gates = len(circuit["gates"])
     eng.init_zero_state()
@@ -244,7 +245,7 @@ def run_single(args, k: int) -> tuple[dict, list[str]]:
     # (the timed steps stand for a run that repeats its plan many times: the layout search is made as for such a run,
     # whatever --steps / --warmup are)
     engine = make_engine(n, 1, 0, int(os.environ.get("LOCAL_RANK", "0")), mode=args.mode,
-                         layout="search" if args.layout == "auto" else args.layout)
+                         layout="search" if args.layout == "auto" else args.layout, tune_on_device=args.layout == "auto")
     engine.init_zero_state()
     plan = engine.plan(circuit, repeats=args.warmup + args.steps)
     for _ in range(args.warmup):

@@ -52,14 +52,16 @@ class SingleGpuEngine:
     rank = 0
     LAYOUT_MIN_QUBITS = 26
     LAYOUT_MIN_REPEATS = 8         # layout = "auto": plans for fewer executions are not worth a second of search
-    LAYOUT_CANDIDATES = 128        # random choices of the three line-bit qubits that are planned and counted
+    LAYOUT_CANDIDATES = 384        # random relabellings (a quarter of them: only the three line-bit qubits) that are planned and counted
+    LAYOUT_FINALISTS = 8           # minimum-pass layouts timed on the device (tune_on_device, |0..0> state only)
 
-    def __init__(self, n_qubits: int, device: int = 0, mode: str = "fused", layout: str = "auto"):
+    def __init__(self, n_qubits: int, device: int = 0, mode: str = "fused", layout: str = "auto", tune_on_device: bool = False):
         if layout not in ("auto", "search", "identity"):
             raise ValueError("layout must be 'auto', 'search' or 'identity'")
         self.n = n_qubits
         self.mode = mode
         self.layout_mode = layout
+        self.tune_on_device = bool(tune_on_device)   # plan(): time the minimum-pass layouts on the device when the state is |0..0>
         self.state = DeviceChunk.empty(n_qubits, device)
         self.l2p: list | None = None        # layout of the state right now (None = identity)
         self._zero = False                  # the state is |0..0>: the same vector in every layout
@@ -114,13 +116,37 @@ class SingleGpuEngine:
             return plan
         import time
         t0 = time.perf_counter()
-        l2p, masks, info = choose_plan_layout(self.n, batches, self.LAYOUT_CANDIDATES)
-        plan = GpuPlan([pack_ops([([l2p[q] for q in qs], U) for qs, U in ops]) for ops in batches])
-        plan.tiles = masks
-        plan.l2p = None if l2p == list(range(self.n)) else l2p
-        plan.model_ms = info["model_ms"]
-        plan.layout_info = dict(info, seconds=round(time.perf_counter() - t0, 3))
-        return plan
+        tune = self.tune_on_device and self._zero            # (timing runs overwrite the state: only |0..0> can be put back)
+        finalists = choose_plan_layout(self.n, batches, self.LAYOUT_CANDIDATES, n_finalists=self.LAYOUT_FINALISTS if tune else 4,
+                                       all_finalists=True)
+
+        def build(l2p, masks, info):
+            plan = GpuPlan([pack_ops([([l2p[q] for q in qs], U) for qs, U in ops]) for ops in batches])
+            plan.tiles = masks
+            plan.l2p = None if l2p == list(range(self.n)) else l2p
+            plan.model_ms = info["model_ms"]
+            plan.layout_info = dict(info)
+            return plan
+        plans = [build(*f) for f in finalists]
+        chosen = plans[0]
+        if tune and len(plans) > 1:
+            # the cost model cannot rank the minimum-pass layouts (measured: 3 % apart, uncorrelated with the model): the
+            # device can -- two timed executions of each on the (zero) state, which is |0..0> again afterwards
+            timed = []
+            for p in plans:
+                self.init_zero_state()
+                self.execute(p)
+                ms = []
+                for _ in range(2):
+                    self.state.time_begin()
+                    self.execute(p)
+                    ms.append(self.state.time_end())
+                timed.append(min(ms))
+            chosen = plans[int(np.argmin(timed))]
+            chosen.layout_info["tuned_on_device_ms"] = [round(t, 3) for t in timed]
+            self.init_zero_state()
+        chosen.layout_info["seconds"] = round(time.perf_counter() - t0, 3)
+        return chosen
 
     def _adopt_layout(self, l2p) -> None:
         """Bring the state into the layout a plan was written for."""
@@ -295,42 +321,46 @@ def _count_passes(n: int, batches, layouts: np.ndarray, threads: int) -> np.ndar
     return total
 
 
-def choose_plan_layout(n: int, batches, n_candidates: int = 128, seed: int = 20260504) -> tuple:
+def choose_plan_layout(n: int, batches, n_candidates: int = 384, seed: int = 20260504, n_finalists: int = 4,
+                       all_finalists: bool = False):
     """(l2p, tile masks per batch on the chosen index bits, info) for the op lists `batches` (logical qubits): the line-bit
     qubits that need the fewest passes among `n_candidates` random choices (the identity included), then the other
-    qubits placed by the tile-cost model (runner/tile_layout.py).  Host only."""
+    qubits placed by the tile-cost model (runner/tile_layout.py).  Host only.  all_finalists: the list of up to
+    n_finalists minimum-pass layouts, best model cost first (the engine may time them on the device)."""
     import os
 
     from quantum_simulations_amd.runner import tile_layout
     rng = np.random.default_rng(seed)
     layouts = np.tile(np.arange(n, dtype=np.int32), (n_candidates + 1, 1))
-    for row in layouts[1:]:
-        for bit, q in enumerate(int(x) for x in rng.choice(n, size=3, replace=False)):
-            j = int(np.flatnonzero(row == bit)[0])          # the qubit on `bit` trades places with q
-            row[j], row[q] = row[q], bit
+    for i, row in enumerate(layouts[1:]):
+        if i % 4 == 0:                                      # a quarter: only the three line-bit qubits change
+            for bit, q in enumerate(int(x) for x in rng.choice(n, size=3, replace=False)):
+                j = int(np.flatnonzero(row == bit)[0])      # the qubit on `bit` trades places with q
+                row[j], row[q] = row[q], bit
+        else:                                               # the rest: every qubit somewhere else (the greedy builder's
+            row[:] = rng.permutation(n)                     # tie-breaks walk the bits in order: other labels, other plans)
     try:
         threads = len(os.sched_getaffinity(0))
     except AttributeError:
         threads = os.cpu_count() or 1
     counts = _count_passes(n, batches, layouts, max(1, min(16, threads)))
     best = int(counts.min())
-    finalists = [int(i) for i in np.flatnonzero(counts == best)][:4]       # (the identity first when it ties)
-    chosen = None
+    finalists = [int(i) for i in np.flatnonzero(counts == best)][:max(1, n_finalists)]   # (the identity first when it ties)
+    out = []
     for f in finalists:
         first = [int(x) for x in layouts[f]]
         moved = [[([first[q] for q in qs], U) for qs, U in ops] for ops in batches]
         masks = [_planned_tile_masks(n, ops) for ops in moved]
         tiles = [[b for b in range(tile_layout.LOW, n) if (int(m) >> b) & 1] for ms in masks for m in ms]
-        cand = min((tile_layout.choose_layout(tiles, n, seed=s) for s in range(1, 9)), key=lambda r: r[2])
-        if chosen is None or cand[2] < chosen[1][2]:
-            chosen = (first, cand, masks)
-    first, (second, cost0, cost1), masks = chosen
-    l2p = [second[first[q]] for q in range(n)]
-    final_masks = [np.array([sum(1 << second[b] for b in range(n) if (int(m) >> b) & 1) for m in ms], dtype=np.uint64) for ms in masks]
-    info = {"passes_identity": int(counts[0]), "passes_chosen": best, "candidates": n_candidates + 1,
-            "candidates_by_passes": {int(c): int((counts == c).sum()) for c in np.unique(counts)},
-            "model_ms": (round(cost0, 3), round(cost1, 3))}
-    return l2p, final_masks, info
+        second, cost0, cost1 = min((tile_layout.choose_layout(tiles, n, seed=s) for s in range(1, 9)), key=lambda r: r[2])
+        l2p = [second[first[q]] for q in range(n)]
+        final_masks = [np.array([sum(1 << second[b] for b in range(n) if (int(m) >> b) & 1) for m in ms], dtype=np.uint64) for ms in masks]
+        info = {"passes_identity": int(counts[0]), "passes_chosen": best, "candidates": n_candidates + 1,
+                "candidates_by_passes": {int(c): int((counts == c).sum()) for c in np.unique(counts)},
+                "model_ms": (round(cost0, 3), round(cost1, 3))}
+        out.append((l2p, final_masks, info))
+    out.sort(key=lambda r: r[2]["model_ms"][1])
+    return out if all_finalists else out[0]
 
 
 def _planned_tile_masks(n: int, ops) -> np.ndarray:
@@ -359,6 +389,7 @@ def _planned_tile_masks(n: int, ops) -> np.ndarray:
 def make_engine(n_qubits: int, world: int = 1, rank: int = 0, local_rank: int = 0,
                 mode: str = "fused", **kw):
     if world == 1:                      # (rehearsal / exchange only mean something with more than one rank)
-        return SingleGpuEngine(n_qubits, device=local_rank, mode=mode, layout=kw.get("layout", "auto"))
+        return SingleGpuEngine(n_qubits, device=local_rank, mode=mode, layout=kw.get("layout", "auto"),
+                               tune_on_device=kw.get("tune_on_device", False))
     from quantum_simulations_amd.runner.distributed import DistributedEngine
     return DistributedEngine(n_qubits, world, rank, local_rank, mode=mode, **kw)

@@ -77,3 +77,28 @@ def test_identity_layout_and_short_plans_skip_the_search():
         eng.close()
     with pytest.raises(ValueError):
         SingleGpuEngine(n, layout="best")
+
+
+def test_tuning_on_the_device_picks_among_minimum_pass_layouts_and_leaves_zero_state():
+    """tune_on_device: the minimum-pass layouts are timed on the device -- allowed only while the state is |0..0>, which it
+    is again afterwards; on a used state the model's first choice is taken without touching the state."""
+    from quantum_simulations_amd.runner.engine import SingleGpuEngine
+    n = 18
+    eng = SingleGpuEngine(n, layout="search", tune_on_device=True)
+    eng.LAYOUT_MIN_QUBITS, eng.LAYOUT_CANDIDATES = 8, 48
+    cd = gen.random_1q_cx_circuit(n, depth=20, seed=5)
+    want = orc.simulate(validate_circuit_dict(cd))
+    eng.init_zero_state()
+    plan = eng.plan(cd)
+    timed = plan.layout_info.get("tuned_on_device_ms")
+    if plan.layout_info["candidates_by_passes"][plan.layout_info["passes_chosen"]] > 1:
+        assert timed and len(timed) >= 2 and all(t > 0 for t in timed)
+    psi = eng.state.download()
+    assert psi[0] == 1.0 and not np.any(psi[1:]) and eng.l2p is None          # |0..0>, identity layout
+    eng.execute(plan)
+    np.testing.assert_allclose(eng.state_vector(), want, rtol=0, atol=1e-10)
+    before = eng.state.download()
+    plan2 = eng.plan(cd)                                                        # a used state: no timing runs
+    assert "tuned_on_device_ms" not in plan2.layout_info
+    np.testing.assert_array_equal(eng.state.download(), before)
+    eng.close()
