@@ -345,6 +345,8 @@ def run_single(args, k: int) -> tuple[dict, list[str]]:
         # parity of the same prefix on the GPU (outside every timed region)
         par = engine.prefix_parity(circuit, done, psi_cpu)
         out["parity_max_abs_diff_vs_cpu_prefix"] = par
+        out["parity_path"] = ("prefix planned like the timed steps: layout search + named tiles, compared through the layout"
+                              if getattr(engine, "last_parity_layout", None) else "prefix through the fused path, identity layout")
         if not par <= PARITY_TOL:
             invalid.append(f"parity vs CPU prefix {par:.3e} > {PARITY_TOL}")
         del psi_cpu

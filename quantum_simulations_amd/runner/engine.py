@@ -265,17 +265,26 @@ class SingleGpuEngine:
                 "bytes": 32 * (1 << self.n), "kernel": "k_copy (read + write, non-temporal above 256 MiB)"}
 
     def prefix_parity(self, circuit_dict: dict, n_gates: int, expected: np.ndarray) -> float:
-        """max |amp - expected| after the first n_gates gates from |0..0> (checker hook for
-        bench.py's CPU leg; runs outside every timed region)."""
+        """max |amp - expected| after the first n_gates gates from |0..0> (checker hook for bench.py's CPU leg; runs
+        outside every timed region) -- through the SAME path as the timed steps: planned by `plan` (layout search and named
+        tiles included, when the engine uses them), executed, compared through the layout."""
         cd = validate_circuit_dict(circuit_dict)
+        prefix = {"number_of_qubits": self.n, "gates": cd["gates"][:n_gates]}
         self.init_zero_state()
-        self.state.apply_ops(gate_ops({"gates": cd["gates"][:n_gates]}))
+        tune, self.tune_on_device = self.tune_on_device, False          # (no timing runs for a check)
+        try:
+            plan = self.plan(prefix, repeats=self.LAYOUT_MIN_REPEATS)
+        finally:
+            self.tune_on_device = tune
+        self.execute(plan)
         worst = 0.0
         step = 1 << 24
         for off in range(0, 1 << self.n, step):
             cnt = min(step, (1 << self.n) - off)
             got = self.state.download(off, cnt)
-            worst = max(worst, float(np.max(np.abs(got - expected[off:off + cnt]))))
+            want = expected[off:off + cnt] if self.l2p is None else expected[self.logical_index(off, cnt)]
+            worst = max(worst, float(np.max(np.abs(got - want))))
+        self.last_parity_layout = None if self.l2p is None else list(self.l2p)
         return worst
 
     def close(self) -> None:
