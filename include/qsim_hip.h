@@ -157,8 +157,8 @@ int qsim_plan_count_layouts(int n_local_qubits, int n_ops, const int32_t* nq, co
  * (bits 0..2 stay) minimising sum over the passes of the caller's cost model of their tile-bit sets (see the .hip for the
  * model's form).  tile_masks[p] = high tile bits of pass p as logical qubits; out_l2p[q] = index bit for qubit q. */
 int qsim_choose_layout(int n_local_qubits, int n_tiles, const uint64_t* tile_masks, int top_bit, const double* bit_cost,
-                       const double* pair_cost, uint64_t seed, int sweeps, int32_t* out_l2p, double* cost_identity,
-                       double* cost_chosen);
+                       const double* pair_cost, const double* triple_cost /* nb^3, a < b < c; may be NULL */, uint64_t seed,
+                       int sweeps, int32_t* out_l2p, double* cost_identity, double* cost_chosen);
 
 /* ---- partner-chunk butterflies (cpu_nonlocal.*) ----------------------------------- */
 int qsim_apply_1q_pair(qsim_chunk* c0, qsim_chunk* c1, const double U[8]);

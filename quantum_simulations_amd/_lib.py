@@ -59,7 +59,7 @@ SIGNATURES = {
     "qsim_plan_ops": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, C.c_uint64, _P]),
     "qsim_plan_ops_tiled": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_uint64, _P]),
     "qsim_apply_ops_tiled": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P]),
-    "qsim_choose_layout": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_uint64, C.c_int, _P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "qsim_choose_layout": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, C.c_uint64, C.c_int, _P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "qsim_plan_count_layouts": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int]),
     "qsim_last_pass_count": (C.c_int, [_P]),
     "qsim_apply_ops_io": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.POINTER(C.c_int)]),

@@ -489,7 +489,8 @@ int qsim_plan_count_layouts(int n_local_qubits, int n_ops, const int32_t* nq, co
 // top_bit priced like top_bit (runner/tile_layout.py holds the coefficients: ridge fits to measured passes).  tile_masks[p] =
 // the high tile bits of pass p as LOGICAL qubits; out_l2p[q] = the index bit chosen for qubit q.  Host only.
 int qsim_choose_layout(int n_local_qubits, int n_tiles, const uint64_t* tile_masks, int top_bit, const double* bit_cost,
-                       const double* pair_cost, uint64_t seed, int sweeps, int32_t* out_l2p, double* cost_identity, double* cost_chosen) {
+                       const double* pair_cost, const double* triple_cost, uint64_t seed, int sweeps, int32_t* out_l2p,
+                       double* cost_identity, double* cost_chosen) {
   const int n = n_local_qubits, low = kTileLow;
   if (n < low + 2 || n > 62 || n_tiles < 0 || (n_tiles && !tile_masks) || !bit_cost || !pair_cost || !out_l2p || top_bit < low || top_bit > 62 || sweeps < 1)
     return fail(QSIM_ERR_INVALID, "qsim_choose_layout: bad arguments");
@@ -504,6 +505,7 @@ int qsim_choose_layout(int n_local_qubits, int n_tiles, const uint64_t* tile_mas
     for (int b = a + 1; b < nb; ++b) sym[(size_t)a * nb + b] = sym[(size_t)b * nb + a] = pair_cost[(size_t)a * nb + b];
   std::vector<int> l2p((size_t)n);
   for (int q = 0; q < n; ++q) l2p[(size_t)q] = q;
+  // (optional third-order terms: triple_cost[(a * nb + b) * nb + c] for a < b < c, zero elsewhere)
   auto cost_of = [&](int t) {
     int idx[64], m = 0;
     for (int q : tiles[(size_t)t]) idx[m++] = std::min(l2p[(size_t)q], top_bit) - low;
@@ -511,6 +513,15 @@ int qsim_choose_layout(int n_local_qubits, int n_tiles, const uint64_t* tile_mas
     for (int i = 0; i < m; ++i) {
       c += bit_cost[idx[i]];
       for (int j = i + 1; j < m; ++j) c += sym[(size_t)idx[i] * nb + idx[j]];
+    }
+    if (triple_cost) {
+      std::sort(idx, idx + m);
+      for (int i = 0; i < m; ++i)
+        for (int j = i + 1; j < m; ++j) {
+          if (idx[j] == idx[i]) continue;
+          const double* row = triple_cost + ((size_t)idx[i] * nb + idx[j]) * nb;
+          for (int l = j + 1; l < m; ++l) if (idx[l] != idx[j]) c += row[idx[l]];
+        }
     }
     return c;
   };

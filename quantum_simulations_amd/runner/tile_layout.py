@@ -31,9 +31,16 @@ def _load_models() -> dict:
     global _models
     if _models is None:
         doc = json.loads(_MODEL_PATH.read_text())
-        _models = {int(k): {"c0": m["c0"], "bit": np.asarray(m["bit"], dtype=np.float64),
-                            "pair": np.asarray(m["pair"], dtype=np.float64), "top": int(m["top"])}
-                   for k, m in doc["models"].items()}
+        _models = {}
+        for k, m in doc["models"].items():
+            nb = int(m["top"]) - LOW + 1
+            tri = None
+            if m.get("tri"):                         # third-order terms [[a, b, c, w], ...] (a < b < c, bit - 3)
+                tri = np.zeros((nb, nb, nb), dtype=np.float64)
+                for a, b, c, w in m["tri"]:
+                    tri[int(a), int(b), int(c)] = w
+            _models[int(k)] = {"c0": m["c0"], "bit": np.asarray(m["bit"], dtype=np.float64),
+                               "pair": np.asarray(m["pair"], dtype=np.float64), "tri": tri, "top": int(m["top"])}
     return _models
 
 
@@ -49,11 +56,17 @@ def tile_cost(model: dict, bits) -> float:
     """Predicted milliseconds (at the model's own state size) of a pass whose tile holds the index bits `bits` (>= 3)."""
     idx = sorted(min(int(b), model["top"]) - LOW for b in bits)
     c = model["c0"] + float(model["bit"][idx].sum())
-    pair = model["pair"]
+    pair, tri = model["pair"], model.get("tri")
     for i, a in enumerate(idx):
-        for b in idx[i + 1:]:
-            if a != b:
-                c += float(pair[a, b])
+        for j in range(i + 1, len(idx)):
+            b = idx[j]
+            if a == b:
+                continue
+            c += float(pair[a, b])
+            if tri is not None:
+                for d in idx[j + 1:]:
+                    if d != b:
+                        c += float(tri[a, b, d])
     return c
 
 
@@ -70,10 +83,12 @@ def choose_layout(tiles: list, n: int, seed: int = 1, sweeps: int = 200) -> tupl
     masks = np.array([sum(1 << int(q) for q in t if q >= LOW) for t in tiles], dtype=np.uint64)
     bit = np.ascontiguousarray(model["bit"], dtype=np.float64)
     pair = np.ascontiguousarray(model["pair"], dtype=np.float64)
+    tri = None if model.get("tri") is None else np.ascontiguousarray(model["tri"], dtype=np.float64)
     out = np.zeros(n, dtype=np.int32)
     c0, c1 = C.c_double(), C.c_double()
     _lib.check(_lib.load().qsim_choose_layout(n, len(masks), masks.ctypes.data_as(C.c_void_p), model["top"],
-                                              bit.ctypes.data_as(C.c_void_p), pair.ctypes.data_as(C.c_void_p), seed, sweeps,
+                                              bit.ctypes.data_as(C.c_void_p), pair.ctypes.data_as(C.c_void_p),
+                                              None if tri is None else tri.ctypes.data_as(C.c_void_p), seed, sweeps,
                                               out.ctypes.data_as(C.c_void_p), C.byref(c0), C.byref(c1)))
     base = model["c0"] * len(tiles)
     return [int(x) for x in out], c0.value + base, c1.value + base

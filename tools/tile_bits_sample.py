@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Gate-less fused pass (load -> store of every tile, probe build) timed for MANY sets of the 8 high tile bits in one
 process: random sets plus structured ones; one line per set "b0 ... b7 ms".  Raw material for a memory-pattern model of
-the pass builder.   python tools/tile_bits_sample.py [n_qubits] [n_random_sets] > gpurun_out/tile_bits_samples.txt"""
+the pass builder.   python tools/tile_bits_sample.py [n_qubits] [n_random_sets] [seed] > gpurun_out/tile_bits_samples.txt"""
 import os
 import sys
 import time
@@ -20,7 +20,7 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
 dev = DeviceChunk.empty(n)
 dev.init_random(1)
 ops = [([3], gt.H()), ([4], gt.H())]
-rng = np.random.default_rng(11)
+rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 11)
 sets = [sorted(int(b) for b in rng.choice(np.arange(3, n), size=8, replace=False)) for _ in range(count)]
 t0 = time.time()
 for i, bits in enumerate(sets):
