@@ -30,3 +30,30 @@ def test_four_ranks_sharing_one_gpu_through_the_launcher():
         for label in labels:
             assert cfg[key][label]["fingerprint_max_abs_diff_vs_single_gpu"] < 1e-10
     assert doc["roofline"]["kernel"].startswith("k_tile") and doc["value"] > 0
+
+
+def test_single_gpu_line_carries_the_contract_fields():
+    """`python3 bench.py` at N = 1 (a small state, short CPU column): ONE JSON line with the fields the driver reads --
+    metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype /
+    data / config.workload, `roofline` {bound, achieved, peak, unit, frac, traffic}, `cpu_baseline` {value, unit, cores,
+    kind, sample} -- exit code 0, no `invalid`; and exit code 2 with a QSIM_* knob in the environment."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE") and not k.startswith("QSIM_")}
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--local-qubits", "22", "--steps", "3", "--warmup", "1", "--no-sweep",
+           "--fused-qubits", "0", "--sustain-seconds", "0", "--cpu-seconds", "2"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and d["roofline"]["bound"] == "hbm"
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
+    assert d["parity_max_abs_diff_vs_cpu_prefix"] < 1e-10 and "invalid" not in d
+    bad = subprocess.run(cmd, cwd=ROOT, env=dict(env, QSIM_PLAN_LOOKAHEAD="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 2 and "refusing" in bad.stdout
