@@ -75,6 +75,12 @@ int qsim_copy(qsim_chunk* dst, const qsim_chunk* src);    /* device-to-device, s
 /* ---- local butterflies (cpu_scalar.apply_1q / apply_2q) --------------------------- */
 int qsim_apply_1q(qsim_chunk* c, int qubit, const double U[8]);
 int qsim_apply_2q(qsim_chunk* c, int qa, int qb, const double U[32]);
+/* Dense k-qubit block (1 <= k <= 4): v3's fused block as a genuine 2^k x 2^k contraction -- `_apply_combined_matrix`,
+ * v3_hisvsim_spark/src/parallel_gate_applicator.py:315-385.  M row-major 2^k x 2^k (re, im interleaved), M[out][in], pattern
+ * bit i <-> qubits[i] (little-endian over the list, :169-204):  new[idx | out] = sum_in M[out][in] old[idx | in].  A block that
+ * is a tensor product of 1q gates is cheaper as butterflies of a fused pass (qsim_apply_ops); this entry is for matrices
+ * that are dense to begin with. */
+int qsim_apply_fused_k(qsim_chunk* c, int k, const int32_t* qubits, const double* M);
 /* A pass of n_ops gates in order (single_node._process_local_chunk, :208-216).
  * nq[i] in {1,2}; qubits[2*i], qubits[2*i+1]; mats + 32*i holds U (8 or 32 doubles). */
 int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits,

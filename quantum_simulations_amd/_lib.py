@@ -54,6 +54,7 @@ SIGNATURES = {
     "qsim_copy": (C.c_int, [_P, _P]),
     "qsim_apply_1q": (C.c_int, [_P, C.c_int, _P]),
     "qsim_apply_2q": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "qsim_apply_fused_k": (C.c_int, [_P, C.c_int, _P, _P]),
     "qsim_apply_ops": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "qsim_apply_ops_unfused": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "qsim_plan_ops": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, C.c_uint64, _P]),

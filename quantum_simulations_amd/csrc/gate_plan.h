@@ -125,8 +125,8 @@ static std::atomic<int> g_prof_open{0};
 static const char* const kClassNames[] = {
     "k_gate<1> scale (diagonal subset)", "k_gate<2> 2x2 butterfly", "k_gate<4> 4x4 butterfly",
     "k_gate_shuffle<1,1> lane 1q", "k_gate_shuffle<1,2> lane 2q", "k_gate_shuffle<2,1> lane+reg 2q",
-    "k_tile fused pass"};
-constexpr int kNumClasses = 7;
+    "k_tile fused pass", "k_dense dense k-qubit block"};
+constexpr int kNumClasses = 8;
 
 static hipEvent_t prof_event_locked() {
   if (!g_prof_pool.empty()) {

@@ -320,6 +320,45 @@ __global__ __launch_bounds__(kBlock) void k_fingerprint(const double2* p, u64 n,
   }
 }
 
+// ---- dense k-qubit block (v3's fused block as a genuine 2^k x 2^k contraction: parallel_gate_applicator.py:315-385) ------
+// A work item owns the 2^K amplitudes that differ in the block's K index bits; new = M old with M row-major in device
+// memory (wave-uniform addresses: scalar loads).  HBM-bound like every gate here (8 * 2^K flop per amplitude over the
+// same 32 B: 2 flop / B at K = 3, 4 at K = 4 -- far under the fp64 ridge); the matrix cores would pay from K ~ 5-6 on
+// (tools/mfma_probe.hip), which no caller of the reference's gate set produces.
+struct DenseArgs {
+  double2* amp;
+  const double2* mat;       // 2^K x 2^K, row-major: M[out][in]
+  u64 count;                // work items = 2^(k - K)
+  int pos[4];               // the block's index bits, ascending (zeros are inserted there)
+  int bit[4];               // pattern bit i <-> index bit bit[i] (the caller's qubit order)
+};
+template <int K, bool NT>
+__global__ __launch_bounds__(kBlock) void k_dense(const DenseArgs a) {
+  constexpr int N = 1 << K;
+  u64 c = logical_block<true>() * kBlock + threadIdx.x;
+  if (c >= a.count) return;
+#pragma unroll
+  for (int i = 0; i < K; ++i) { const int p = a.pos[i]; c = ((c >> p) << (p + 1)) | (c & ((1ull << p) - 1)); }
+  double2 x[N];
+#pragma unroll
+  for (int s = 0; s < N; ++s) {
+    u64 off = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) off |= (u64)((s >> i) & 1) << a.bit[i];
+    x[s] = ld_amp<NT>(a.amp + (c | off));
+  }
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    double2 acc = cmul(a.mat[r * N], x[0]);
+#pragma unroll
+    for (int col = 1; col < N; ++col) acc = cfma(a.mat[r * N + col], x[col], acc);
+    u64 off = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) off |= (u64)((r >> i) & 1) << a.bit[i];
+    st_amp<NT>(a.amp + (c | off), acc);
+  }
+}
+
 static int ensure_scratch(qsim_chunk* c) {
   if (!c->scratch) {
     HIP_TRY(hipSetDevice(c->device));

@@ -359,6 +359,50 @@ int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* q
   return rc;
 }
 
+// Dense k-qubit block: new[idx with the block's bits = out] = sum_in M[out][in] old[idx with the block's bits = in], pattern
+// bit i <-> qubits[i] -- v3's `_apply_combined_matrix` (parallel_gate_applicator.py:315-385) for a genuinely dense 2^k x 2^k
+// matrix (its tensor-product blocks are cheaper as butterflies inside a fused pass: qsim_apply_ops).  1 <= k <= 4.
+int qsim_apply_fused_k(qsim_chunk* c, int k, const int32_t* qubits, const double* M) {
+  int rc = check_chunk(c, "qsim_apply_fused_k");
+  if (rc) return rc;
+  if (!qubits || !M) return fail(QSIM_ERR_INVALID, "qsim_apply_fused_k: null argument");
+  if (k < 1 || k > 4) return fail(QSIM_ERR_INVALID, "qsim_apply_fused_k: 1 <= k <= 4 qubits expected, got %d", k);
+  if (parts_pending(c)) return fail(QSIM_ERR_INVALID, "qsim_apply_fused_k: slab pieces of a split qsim_apply_ops_io call are pending on this chunk");
+  for (int i = 0; i < k; ++i) {
+    if ((rc = check_local_qubit(c, qubits[i]))) return rc;
+    for (int j = 0; j < i; ++j) if (qubits[j] == qubits[i]) return fail(QSIM_ERR_INVALID, "qsim_apply_fused_k: repeated qubit %d", qubits[i]);
+  }
+  if (k == 1) return qsim_apply_1q(c, qubits[0], M);
+  if (k == 2) return qsim_apply_2q(c, qubits[1], qubits[0], M);   // pattern = bit(q0) + 2 bit(q1) = the pair index with qa = q1
+  HIP_TRY(hipSetDevice(c->device));
+  if ((rc = ensure_scratch(c))) return rc;
+  const int N = 1 << k;
+  static_assert(kReduceBlocks * sizeof(double) >= 16 * 16 * sizeof(double2), "the chunk's scratch holds a 16 x 16 complex matrix");
+  HIP_TRY(hipMemcpyAsync(c->scratch, M, sizeof(double2) * (size_t)N * N, hipMemcpyHostToDevice, c->stream));
+  DenseArgs a;
+  a.amp = c->amp;
+  a.mat = reinterpret_cast<const double2*>(c->scratch);
+  a.count = amps(c) >> k;
+  int sorted[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) { a.bit[i] = i < k ? qubits[i] : 0; sorted[i] = i < k ? qubits[i] : 0; }
+  std::sort(sorted, sorted + k);
+  for (int i = 0; i < 4; ++i) a.pos[i] = sorted[i];
+  const bool nt = c->span_bytes > tuning().mall_bytes && sorted[0] >= kLaneCut;
+  u64 blocks = (a.count + kBlock - 1) / kBlock;
+  blocks = (blocks + 7) & ~7ull;                     // whole octets: logical_block<true> deals blocks over the 8 XCDs
+  ProfileScope prof(7, 32.0 * (double)amps(c), c->stream, nt);
+  if (k == 3) {
+    if (nt) hipLaunchKernelGGL((k_dense<3, true>), grid_for(blocks), dim3(kBlock), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_dense<3, false>), grid_for(blocks), dim3(kBlock), 0, c->stream, a);
+  } else {
+    if (nt) hipLaunchKernelGGL((k_dense<4, true>), grid_for(blocks), dim3(kBlock), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_dense<4, false>), grid_for(blocks), dim3(kBlock), 0, c->stream, a);
+  }
+  prof.done(c->stream);
+  HIP_TRY(hipGetLastError());
+  return QSIM_OK;
+}
+
 // qsim_apply_ops with the high tile bits of the first n_tiles passes named by the caller (bit b of tile_masks[p]: index bit b
 // is a tile bit of pass p): the pass builder takes them instead of searching; a mask that holds no op is ignored.
 int qsim_apply_ops_tiled(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,

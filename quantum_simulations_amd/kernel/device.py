@@ -139,6 +139,15 @@ class DeviceChunk:
         m, p = _mat_ptr(U, 4)
         _lib.check(_lib.load().qsim_apply_2q(self._h, int(qa), int(qb), p))
 
+    def apply_fused_k(self, qubits, M: np.ndarray) -> None:
+        """Dense k-qubit block (qsim_apply_fused_k, k <= 4): M is 2^k x 2^k, M[out, in], pattern bit i <-> qubits[i] --
+        v3's `_apply_combined_matrix` (parallel_gate_applicator.py:315-385) on the dense state."""
+        q = np.asarray(qubits, dtype=np.int32)
+        m = np.ascontiguousarray(M, dtype=np.complex128)
+        if m.shape != (1 << len(q), 1 << len(q)):
+            raise ValueError(f"a {len(q)}-qubit block needs a {1 << len(q)} x {1 << len(q)} matrix, got {m.shape}")
+        _lib.check(_lib.load().qsim_apply_fused_k(self._h, len(q), q.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p)))
+
     def apply_ops_tiled(self, ops, tile_masks) -> int:
         """`apply_ops` (fused) with the high tile bits of the first passes given (qsim_apply_ops_tiled): `tile_masks` =
         uint64 array, bit b of entry p = index bit b is a tile bit of pass p.  Returns the HBM round trips."""

@@ -754,3 +754,67 @@ def test_plan_cache_reuses_plans_and_tells_op_lists_apart(hip):
     np.testing.assert_allclose(big.download(), want, rtol=0, atol=1e-11)
     for c in (a, b, send, recv, big):
         c.close()
+
+
+def test_dense_k_qubit_block_against_the_oracle(hip):
+    """qsim_apply_fused_k (v3's fused block as a genuine 2^k x 2^k contraction, parallel_gate_applicator.py:315-385):
+    random dense unitaries on 1-4 qubits in random order -- line bits included -- on chunks of 4 to 2^20 amplitudes, on a
+    small view of a 512 MiB parent (the streaming instantiation), the tensor-product block of v3 through it, and the
+    argument checks."""
+    from quantum_simulations_amd.parallel_gate_applicator import ParallelGateApplicator, tensor_product_single_qubits
+    rng = np.random.default_rng(77)
+
+    def unitary(dim):
+        return np.linalg.qr(rng.standard_normal((dim, dim)) + 1j * rng.standard_normal((dim, dim)))[0]
+    for n in (2, 4, 7, 11, 16, 20):
+        psi0 = _rand_state(n, 500 + n)
+        dev = hip.DeviceChunk.from_numpy(psi0)
+        for k in range(1, min(4, n) + 1):
+            for trial in range(6 if n <= 16 else 2):
+                qs = [int(q) for q in rng.choice(n, size=k, replace=False)]
+                if trial == 0:
+                    qs = list(range(k))                      # all inside one 128-byte line (k <= 3) / the lowest bits
+                M = unitary(1 << k)
+                want = psi0.copy()
+                orc.apply_kq(want, qs, M)
+                dev.upload(psi0)
+                dev.apply_fused_k(qs, M)
+                np.testing.assert_allclose(dev.download(), want, rtol=0, atol=ATOL_KERNEL, err_msg=f"n={n} qubits={qs}")
+        dev.close()
+    # streaming instantiation: a 2^14 view inside a 512 MiB allocation
+    parent = hip.DeviceChunk.empty(25)
+    view = parent.view(3 << 14, 14)
+    psi0 = _rand_state(14, 9)
+    for qs in ([3, 9, 12], [13, 5, 8, 10], [0, 6, 11]):
+        M = unitary(1 << len(qs))
+        want = psi0.copy()
+        orc.apply_kq(want, qs, M)
+        view.upload(psi0)
+        view.profile_begin()
+        view.apply_fused_k(qs, M)
+        prof = view.profile_end()
+        np.testing.assert_allclose(view.download(), want, rtol=0, atol=ATOL_KERNEL, err_msg=str(qs))
+        entry = [e for e in prof if e["kernel"].startswith("k_dense")]
+        assert len(entry) == 1 and entry[0]["launches"] == 1 and entry[0]["streaming_launches"] == (1 if min(qs) >= 3 else 0)
+    view.close()
+    parent.close()
+    # v3's tensor-product block through the dense entry == the same gates one by one
+    n = 12
+    psi0 = _rand_state(n, 3)
+    dev = hip.DeviceChunk.from_numpy(psi0)
+    qubits = [9, 2, 5]
+    mats = {q: unitary(2) for q in qubits}
+    ParallelGateApplicator().apply_combined_matrix(dev, sorted(qubits), tensor_product_single_qubits(qubits, mats))
+    want = psi0.copy()
+    for q in qubits:
+        orc.apply_1q(want, q, mats[q])
+    np.testing.assert_allclose(dev.download(), want, rtol=0, atol=ATOL_KERNEL)
+    with pytest.raises(NotImplementedError, match="non-local"):
+        dev.apply_fused_k([0, n, 3], np.eye(8))
+    with pytest.raises(ValueError):
+        dev.apply_fused_k([0, 1, 1], np.eye(8))
+    with pytest.raises(ValueError):
+        dev.apply_fused_k([0, 1, 2, 3, 4], np.eye(32))
+    with pytest.raises(ValueError):
+        dev.apply_fused_k([0, 1, 2], np.eye(4))
+    dev.close()

@@ -125,3 +125,36 @@ def test_permute_state_matches_reference():
     for case in jdoc("planner.json")["permute"]:
         got = orc.permute_state(c128(case["in"]), case["log_to_phys"])
         np.testing.assert_array_equal(got, c128(case["out"]))
+
+
+def test_dense_k_qubit_block_is_pinned_through_the_pinned_kernels():
+    """oracle.apply_kq restates v3's `_apply_combined_matrix` (Spark cannot run here): a Kronecker product of 1q matrices
+    must equal the pinned `apply_1q` on every qubit (that IS v3's fused block, parallel_gate_applicator.py:169-204), and a
+    4x4 the pinned `apply_2q` with qubits[1] as the pair's MSB."""
+    from oracle import dense_oracle as orc
+    rng = np.random.default_rng(8)
+    n = 9
+    psi0 = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    for k in (1, 2, 3, 4):
+        for _ in range(6):
+            qs = [int(q) for q in rng.choice(n, size=k, replace=False)]
+            mats = [np.linalg.qr(rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2)))[0] for _ in qs]
+            M = np.array([[1.0]], dtype=complex)
+            for U in mats:                                   # pattern bit i <-> qubits[i]: later factors are more significant
+                M = np.kron(U, M)
+            a, b = psi0.copy(), psi0.copy()
+            orc.apply_kq(a, qs, M)
+            for q, U in zip(qs, mats):
+                orc.apply_1q(b, q, U)
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-13)
+    for _ in range(6):
+        qs = [int(q) for q in rng.choice(n, size=2, replace=False)]
+        U = np.linalg.qr(rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4)))[0]
+        a, b = psi0.copy(), psi0.copy()
+        orc.apply_kq(a, qs, U)
+        orc.apply_2q(b, qs[1], qs[0], U)
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-13)
+    with pytest.raises(NotImplementedError, match="non-local"):
+        orc.apply_kq(psi0.copy(), [0, n], np.eye(4))
+    with pytest.raises(ValueError):
+        orc.apply_kq(psi0.copy(), [0, 1], np.eye(8))
