@@ -487,8 +487,9 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
 
 
 # ---------------------------------------------------------------------------------- launcher-free N > 1
-def launch_ranks(n: int) -> int:
-    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks from here.
+def launch_ranks(n: int, script=None) -> int:
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks from here (`script`: another
+    entry point started the same way, tools/run_config.py --ranks N).
 
     The parent (this process) makes NO GPU call -- no torch import, no library load -- picks a free port, starts N fresh
     interpreters of this script (never exec: each child is a new process that initialises its own GPU), relays what rank 0
@@ -515,7 +516,7 @@ def launch_ranks(n: int) -> int:
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_RANKS_STARTED_BY="bench.py")
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, str(Path(script or __file__).resolve())] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, preexec_fn=die_with_parent))
 
     def relay(pipe):

@@ -110,6 +110,11 @@ int qsim_apply_ops_tiled(qsim_chunk* c, int n_ops, const int32_t* nq, const int3
  *   dst  != NULL: after the ops the state is left in `dst` in the slab layout over dst_bits -- except slab
  *                 own_pattern (>= 0), which is left at its place in `dst_own` (the receive buffer: that slab stays
  *                 on this rank); the chunk's own contents are unspecified afterwards.
+ *                 dst_own may be the SOURCE buffer (a rank then needs three shard-sized buffers, not four: the source
+ *                 has been consumed when a later kernel stores the own slab).  When ONE pass reads the source and
+ *                 stores the slabs, the own slab goes into the chunk itself instead (at the same place): ask
+ *                 qsim_apply_ops_io_own_slab after the call -- the exchange then delivers into the chunk, and the
+ *                 chunk and the source buffer trade roles.
  * Parts that cannot be fused (a slab bit inside a 128-byte line, fewer qubits than a tile holds, no ops, a slab bit
  * among the tile bits of the last pass) run as separate slab passes; *n_passes reports the HBM passes made. */
 typedef struct {
@@ -136,6 +141,7 @@ typedef struct {
 } qsim_ops_io;
 int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits,
                       const double* mats, const qsim_ops_io* io, int* n_passes);
+int qsim_apply_ops_io_own_slab(const qsim_chunk* c, int32_t* in_chunk);   /* 1: the last call left the own slab in the chunk */
 int qsim_apply_ops_io_load(qsim_chunk* c, int part);
 int qsim_apply_ops_io_source_parts(const qsim_chunk* c, int32_t* n_parts, uint64_t* piece_amps, int32_t* n_launches);
 /* Pieces of the pending split call: piece j of EVERY slab d is [d * 2^(k - m) + j * piece_amps, + piece_amps) of the send /

@@ -68,6 +68,7 @@ SIGNATURES = {
     "qsim_apply_ops_io_load": (C.c_int, [_P, C.c_int]),
     "qsim_apply_ops_io_source_parts": (C.c_int, [_P, _P, _P, _P]),
     "qsim_apply_ops_io_parts": (C.c_int, [_P, _P, _P, _P]),
+    "qsim_apply_ops_io_own_slab": (C.c_int, [_P, _P]),
     "qsim_split_piece_count": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "qsim_apply_1q_pair": (C.c_int, [_P, _P, _P]),
     "qsim_apply_2q_pair_qa_local": (C.c_int, [_P, _P, C.c_int, _P]),

@@ -36,6 +36,7 @@ struct qsim_chunk {
   u64 span_bytes;        // size of the allocation the chunk lives in (cache-policy choice)
   struct PendingLast* pending;   // split form of qsim_apply_ops_io: the slab-storing pass, planned but not yet launched (owned)
   struct DeferredIo* deferred;   // an op list whose source arrives in pieces (qsim_ops_io::src_parts): planned, not yet launched (owned)
+  bool own_in_chunk;     // the last qsim_apply_ops_io stored its own slab into THIS chunk (dst_own == src, one pass): qsim_apply_ops_io_own_slab
 };
 
 static const int kMaxDevices = 16;

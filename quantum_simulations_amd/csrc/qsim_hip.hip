@@ -867,6 +867,7 @@ static int apply_ops_io_deferred(qsim_chunk* c, int n_ops, const int32_t* nq, co
     int p = 0;
     if ((rc = run_fused(c, ops, &p, &d->fio, n_ops, nq, qubits, mats, &d->passes))) return rc;
     passes += p;
+    c->own_in_chunk = d->fio.own_in_chunk;
     if (d->fio.src && !d->fio.fused_in) return fail(QSIM_ERR_INVALID, "internal: the first pass did not take the source buffer");
     // the first pass in partial launches: when it reads the source itself, is not also the slab-storing pass of a split
     // / fused destination, and the top piece bits are no tile bits of it
@@ -918,8 +919,10 @@ int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t
     if (io->own_pattern < -1 || io->own_pattern >= (1 << io->dst_m)) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: own_pattern out of range");
     if (io->own_pattern >= 0 && (rc = check_side(io->dst_own, io->dst_m, io->dst_bits, "own-slab"))) return rc;
     if (io->own_pattern >= 0 && io->dst_own->amp == io->dst->amp) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: the own-slab buffer must differ from the destination");
-    if (io->src && (io->src->amp == io->dst->amp || (io->own_pattern >= 0 && io->src->amp == io->dst_own->amp)))
-      return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: the source buffer must differ from the destination buffers (one pass may read and write them at once)");
+    if (io->src && io->src->amp == io->dst->amp)
+      return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: the source buffer must differ from the destination buffer (one pass may read and write them at once)");
+    // (dst_own == src is allowed: with two or more kernels the source has been consumed before the own slab is stored;
+    // when ONE pass does everything the own slab goes into the chunk instead -- qsim_apply_ops_io_own_slab tells)
   }
   HIP_TRY(hipSetDevice(c->device));
   std::vector<FusedOp> ops;
@@ -944,6 +947,7 @@ int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t
     for (int i = 0; i < io->dst_m; ++i) fio.out.bits[i] = io->dst_bits[i];
   }
   const bool parts = io->dst && io->dst_parts != 0;
+  c->own_in_chunk = false;
   if (parts_pending(c))
     return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: pieces of an earlier split call are pending on this chunk (qsim_apply_ops_io_part / _load)");
   fio.parts = parts;
@@ -957,6 +961,7 @@ int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t
     int p = 0;
     if ((rc = run_fused(c, ops, &p, &fio, n_ops, nq, qubits, mats))) return rc;
     passes += p;
+    c->own_in_chunk = fio.own_in_chunk;
     if (fio.src && !fio.fused_in) return fail(QSIM_ERR_INVALID, "internal: the first pass did not take the source buffer");
   } else {
     if ((rc = qsim_apply_ops_unfused(c, n_ops, nq, qubits, mats))) return rc;
@@ -1062,6 +1067,14 @@ int qsim_apply_ops_io_load(qsim_chunk* c, int part) {
   }
   if ((rc = finish_out_side(c, io, d->fio))) return rc;
   guard.armed = false;
+  return QSIM_OK;
+}
+
+// Where the last qsim_apply_ops_io on this chunk left the slab that stays on the rank: 0 = in io->dst_own, 1 = in the chunk
+// itself (dst_own was the source buffer and one pass did everything; the exchange then has to deliver into the chunk).
+int qsim_apply_ops_io_own_slab(const qsim_chunk* c, int32_t* in_chunk) {
+  if (!c || !in_chunk) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io_own_slab: null argument");
+  *in_chunk = c->own_in_chunk ? 1 : 0;
   return QSIM_OK;
 }
 

@@ -1125,6 +1125,7 @@ struct FusedIo {
   bool parts = false;                // the slab-storing pass is not launched here: it is left pending in the chunk and
                                      // launched slab by slab (qsim_apply_ops_io_part), so each slab's exchange can start early
   bool fused_in = false, fused_out = false;   // results
+  bool own_in_chunk = false;         // result: the own slab went into the chunk itself (dst_own == src and ONE pass does it all)
 };
 
 // The slab-storing pass of an op list whose caller asked for the split form (qsim_ops_io::dst_parts): planned, not yet
@@ -1199,6 +1200,13 @@ static void prepare_planned(qsim_chunk* c, TileArgs& a, int T, bool first, bool 
       if (io->own_pattern >= 0) {
         a.perm |= kTileOwnOut;
         a.amp_out_own = io->dst_own->amp;
+        if (first && io->src && io->dst_own->amp == io->src->amp) {
+          // ONE pass reads the source buffer and stores the slabs, and the caller named the source as the place of the
+          // slab that stays (three shard-sized buffers per rank instead of four): a tile of that slab must not overwrite
+          // source lines other tiles still read -- it goes into the chunk itself, whose contents nobody needs now
+          a.amp_out_own = c->amp;
+          io->own_in_chunk = true;
+        }
         a.own_mask = a.own_value = 0;
         for (int i = 0; i < io->out.m; ++i) {
           a.own_mask |= 1ull << io->out.bits[i];

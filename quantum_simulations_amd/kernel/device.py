@@ -179,8 +179,8 @@ class DeviceChunk:
     def apply_ops_io(self, ops, src=None, dst=None, parts: int = 0, src_parts: int = 0) -> int:
         """`apply_ops` with a re-layout fused into its ends (qsim_apply_ops_io): `src` = (chunk, bits): the state
         is read from that chunk in the slab layout of `pack_all` over `bits`; `dst` = (chunk, bits, own_chunk,
-        own_pattern): it is left in `chunk` in slab layout, slab `own_pattern` (>= 0) in `own_chunk`.  Returns the
-        HBM passes made.  `parts` = 2, 4, 8 (with `dst`): split form -- the slabs are NOT stored by this call but piece
+        own_pattern): it is left in `chunk` in slab layout, slab `own_pattern` (>= 0) in `own_chunk` -- which may be the
+        source chunk: see `own_slab_in_chunk`.  Returns the HBM passes made.  `parts` = 2, 4, 8 (with `dst`): split form -- the slabs are NOT stored by this call but piece
         by piece by `store_part(j)` for every j < len(`pending_parts()`), so that each piece's exchange can be posted
         while the later pieces are still computed (negative: no 2^20-amplitude floor on a piece, for tests).
         `src_parts` (with `src`): the source arrives in the pieces of the same rule: this call only plans; announce every
@@ -210,6 +210,13 @@ class DeviceChunk:
         _lib.check(_lib.load().qsim_apply_ops_io(self._h, len(nq), nq.ctypes.data_as(C.c_void_p), qs.ctypes.data_as(C.c_void_p),
                                                  mats.ctypes.data_as(C.c_void_p), C.byref(io), C.byref(passes)))
         return passes.value
+
+    def own_slab_in_chunk(self) -> bool:
+        """True when the last `apply_ops_io` left the slab that stays on the rank in THIS chunk instead of `own_chunk`
+        (own_chunk was the source chunk and one pass did everything; qsim_apply_ops_io_own_slab)."""
+        flag = C.c_int32()
+        _lib.check(_lib.load().qsim_apply_ops_io_own_slab(self._h, C.byref(flag)))
+        return bool(flag.value)
 
     def pending_parts(self) -> list:
         """Pieces of the pending split `apply_ops_io`: [(offset, amplitudes), ...] -- piece j of EVERY slab d is that

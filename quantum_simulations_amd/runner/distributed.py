@@ -112,6 +112,17 @@ class HipShardBackend:
                                dst=(self.chunk(dst[0]), dst[1], self.chunk(dst[2]), dst[3]) if dst else None, parts=parts,
                                src_parts=src_parts)
 
+    def own_slab_in_state(self) -> bool:
+        """The last `apply_ops` with a `dst` whose own-slab buffer was the source buffer left that slab in "state" (one
+        pass read the source and stored the slabs: qsim_apply_ops_io_own_slab)."""
+        return self.chunk("state").own_slab_in_chunk()
+
+    def swap_names(self, a: str, b: str) -> None:
+        """Buffers `a` and `b` trade names (the shard's home moves: the engine addresses buffers by role)."""
+        self.tensor(a), self.tensor(b)
+        self._tensors[a], self._tensors[b] = self._tensors[b], self._tensors[a]
+        self._chunks[a], self._chunks[b] = self._chunks[b], self._chunks[a]
+
     def load_part(self, j: int) -> None:
         self.chunk("state").load_part(j)
 
@@ -245,7 +256,16 @@ class DryBackend:
         self.local_passes += 1
         if dst is not None and parts:
             self._parts = split_pieces(self.k, len(dst[1]), parts)
+        # (a dry run knows no pass counts: it takes the one-pass branch -- own slab into "state", buffers trade names --
+        # whenever the engine offers it, which exercises the role bookkeeping; the transfers are the same either way)
+        self._own_in_state = src is not None and dst is not None and dst[2] == src[0]
         return 1
+
+    def own_slab_in_state(self) -> bool:
+        return self._own_in_state
+
+    def swap_names(self, a: str, b: str) -> None:
+        pass
 
     def pending_parts(self) -> list:
         return self._parts
@@ -333,6 +353,7 @@ class DistributedEngine:
             raise ValueError("relayout_pieces must be 1, 2, 4 or 8")
         self.relayout_pieces, self.min_piece_qubits = relayout_pieces, min_piece_qubits
         self._passes = self.last_passes = 0
+        self.home_moves = 0                        # times "state" and "buf1" traded names (one-pass op list between two re-layouts)
         self._pending: list = []
         # Re-layout fused with the neighbouring local passes (round 3): the last fused pass before an exchange stores
         # its tiles straight into the send buffer in slab order and the first one after it loads them from the
@@ -343,16 +364,17 @@ class DistributedEngine:
         # ... and, while the pieces of that re-layout may still be on the links, `_inflight` = (posted groups, timer): the
         # next reader of the shard consumes them piece by piece (its first pass starts on the tiles whose pieces are there)
         self._inflight = None
-        # Memory per rank: the shard + the send buffer + TWO receive buffers that take turns (a pass that reads the shard
-        # from one receive buffer stores its own slab into the other) = 4 shard-sized allocations with fused re-layouts
-        # (64 GiB at 30 local qubits), 3 without.  Claimed here, not in the middle of a circuit.
+        # Memory per rank: the shard + the send buffer + the receive buffer = 3 shard-sized allocations (48 GiB at 30 local
+        # qubits, 192 GiB at 32), fused re-layouts or not: a pass that reads the shard from the receive buffer and stores
+        # the next re-layout's slabs leaves its own slab in "state" (free at that time) and the two buffers trade names
+        # (`relayout`); round 3 kept a second receive buffer for that.  Claimed here, not in the middle of a circuit.
         if not self.dry and hasattr(self.backend, "tensor"):
             try:
-                for name in ("buf0", "buf1") + (("buf2",) if fuse_relayout else ()):
+                for name in ("buf0", "buf1"):
                     self.backend.tensor(name)
             except RuntimeError as e:        # torch's out-of-memory error is a RuntimeError
-                raise MemoryError(f"rank {rank}: no room for the exchange buffers ({4 if fuse_relayout else 3} x "
-                                  f"{16 << self.k} bytes per rank are needed with fuse_relayout={fuse_relayout}): {e}") from e
+                raise MemoryError(f"rank {rank}: no room for the exchange buffers (3 x {16 << self.k} bytes per rank are "
+                                  f"needed): {e}") from e
 
     # ---- layout ------------------------------------------------------------------------
     @property
@@ -640,8 +662,7 @@ class DistributedEngine:
         if self.fuse_relayout and min(loc) >= 3 and self.k - m >= 3:
             # Fused: the queued local ops' last pass writes the slabs (own slab straight into the receive buffer), the next
             # local pass will read them from there.  (A slab bit inside a 128-byte line would break whole-line accesses:
-            # the unfused path below handles it.)  The receive buffer must not be the one the shard currently lives in (a
-            # one-pass op list would read and write it at once): a third buffer takes turns.
+            # the unfused path below handles it.)
             # What overlaps what: the slab-storing pass is cut into up to `relayout_pieces` PIECES
             # (the j-th equal sub-range of every slab: qsim_ops_io::dst_parts) and the exchange of piece j -- one group
             # with all 2^m - 1 peers, every link busy -- is posted as soon as piece j is stored, so it travels while the
@@ -651,17 +672,27 @@ class DistributedEngine:
             # pieces ready at once: it overlaps less, it does not post differently).  The first pass AFTER the exchange
             # takes the pieces over as they arrive (`_inflight`, qsim_ops_io::src_parts): it runs on the tiles whose
             # pieces are there -- when the piece bits are no tile bits of it -- while the later pieces are on the links.
-            rname = "buf2" if (self._state_in is not None and self._state_in[0] == "buf1") else "buf1"
+            # Buffers: the slabs go into "buf0", the slab that stays straight into the receive buffer "buf1" -- also when
+            # the shard currently LIVES in "buf1" (two re-layouts with little between them): with two or more kernels "buf1"
+            # has been consumed by the first before the last stores into it; when ONE pass reads "buf1" and stores the
+            # slabs, the library leaves the own slab in "state" instead (nobody needs its contents then), the exchange
+            # delivers into "state", and "state" and "buf1" trade names afterwards: the shard is in "buf1" again and the
+            # consumed buffer is the new home.  Three shard-sized buffers per rank in every case.
+            from_recv = self._state_in is not None and self._state_in[0] == "buf1"
             ops, self._pending = self._pending, []
-            self._run_local(ops, dst=("buf0", loc, rname, mine), parts=self._split_parts())
+            self._run_local(ops, dst=("buf0", loc, "buf1", mine), parts=self._split_parts())
+            rname = "state" if (from_recv and self.backend.own_slab_in_state()) else "buf1"
             timer = self._comm_timer(send)
             posted = []
             for j, (off, cnt) in enumerate(self.backend.pending_parts()):
                 self.backend.store_part(j)
                 posted.append(self._post("buf0", rname, [(peer, d * slab + 2 * off, 2 * cnt) for d, peer in peers]))
+            if rname == "state":
+                self.backend.swap_names("state", "buf1")       # (posted transfers hold the buffers themselves, not the names)
+                self.home_moves += 1
             # nobody waits here: the next reader of the shard takes the pieces over as they arrive (_run_local)
             self._inflight = (posted, timer)
-            self._state_in = (rname, list(loc))
+            self._state_in = ("buf1", list(loc))
             return
         self._flush_local()
         self._passes += 2

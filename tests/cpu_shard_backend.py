@@ -99,12 +99,28 @@ class CpuShardBackend:
             self._deferred = None
             self._apply_now(ops, src, dst, parts)
 
+    def own_slab_in_state(self) -> bool:
+        return self._own_in_state
+
+    def swap_names(self, a: str, b: str) -> None:
+        self.tensor(a), self.tensor(b)
+        self._t[a], self._t[b] = self._t[b], self._t[a]
+
+    _own_in_state = False
+
     def _apply_now(self, ops, src, dst, parts) -> None:
         if src is not None:
             self.unpack_all(src[1], src[0], -1)
+            self._c(src[0])[:] = np.nan           # consumed: nobody may read it again
         orc.apply_ops(self._c("state"), ops)
+        self._own_in_state = False
         if dst is not None:
             buf, bits, own_buf, own = dst
+            if src is not None and own_buf == src[0] and own >= 0 and len(ops) <= 6:
+                # the library's one-pass case (qsim_apply_ops_io_own_slab): a short op list between two re-layouts is ONE
+                # pass that reads the source and stores the slabs -- the own slab goes into "state" instead.  (Rank
+                # dependent, like the real thing: the ranks' op lists differ by their rank-bit phases.)
+                own_buf, self._own_in_state = "state", True
             slab = 1 << (self.k - len(bits))
             if parts:
                 # split form (qsim_ops_io::dst_parts): nothing is stored yet -- piece j of every slab by store_part(j)
@@ -112,11 +128,13 @@ class CpuShardBackend:
                 self._parts = split_pieces(self.k, len(bits), parts)
                 self._split = (buf, list(bits), own_buf, own, len(self._parts), self._c("state").copy())
                 self._stored = set()
+                self._c("state")[:] = np.nan      # unspecified afterwards: nobody may read it before the next src
             else:
                 self.pack_all(bits, buf, own)
+                mine = self._c("state")[self._slab_index(bits, own)] if own >= 0 else None
+                self._c("state")[:] = np.nan
                 if own >= 0:
-                    self._c(own_buf)[own * slab:(own + 1) * slab] = self._c("state")[self._slab_index(bits, own)]
-            self._c("state")[:] = np.nan          # unspecified afterwards: nobody may read it before the next src
+                    self._c(own_buf)[own * slab:(own + 1) * slab] = mine
 
     def pending_parts(self) -> list:
         return self._parts

@@ -49,7 +49,7 @@ def _circuits(n):
     }
 
 
-def _worker(rank, world, port, n, staging_modes, errors):
+def _worker(rank, world, port, n, staging_modes, errors, moves=None):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                           RANK=str(rank), WORLD_SIZE=str(world))
@@ -85,6 +85,8 @@ def _worker(rank, world, port, n, staging_modes, errors):
                     (orc.apply_1q if len(g["qubits"]) == 1 else orc.apply_2q)(want2, *g["qubits"], U)
                 err2 = float(np.max(np.abs(eng.state_vector() - want2)))
                 assert err2 < 1e-12, f"{name} repeat staging={staging}/{method}: {err2}"
+            if moves is not None:
+                moves.put(eng.home_moves)
             eng.backend.close()
         eng.close()
     except Exception:
@@ -92,11 +94,11 @@ def _worker(rank, world, port, n, staging_modes, errors):
         raise
 
 
-def _run(world, n, staging_modes):
+def _run(world, n, staging_modes, expect_home_moves=False):
     ctx = mp.get_context("spawn")
-    errors = ctx.SimpleQueue()
+    errors, moves = ctx.SimpleQueue(), ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, staging_modes, errors))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, staging_modes, errors, moves))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -111,6 +113,13 @@ def _run(world, n, staging_modes):
             p.join(10)
             msgs.append((-1, "worker still running after 300 s (hung collective?): killed"))
     assert not msgs and all(p.exitcode == 0 for p in procs), "\n".join(f"[rank {r}] {m}" for r, m in msgs)
+    total = 0
+    while not moves.empty():
+        total += moves.get()
+    if expect_home_moves:
+        # a short op list between two fused re-layouts reads the receive buffer and stores the next slabs in ONE pass: its
+        # own slab goes into "state" and the two buffers trade names (three shard-sized buffers per rank, not four)
+        assert total > 0, "no re-layout took the one-pass branch: the role swap of state / buf1 was not exercised"
 
 
 MODES = [(True, "belady"), (True, "heuristic"), (True, "greedy"), (False, "heuristic"), (True, "belady", False),
@@ -124,7 +133,7 @@ def test_world2_gloo():
 def test_world2_gloo_larger_shards():
     """7 local qubits: most re-layout bits lie above the line bits, so the fused path (slabs written by the last local
     pass, read by the next) carries nearly every exchange."""
-    _run(2, 8, [(True, "belady"), (False, "heuristic")])
+    _run(2, 8, [(True, "belady"), (False, "heuristic")], expect_home_moves=True)
 
 
 def test_world4_gloo():
@@ -137,7 +146,7 @@ def test_world8_gloo():
 
 def test_world8_gloo_larger_shards():
     """8 ranks x 7 local qubits: three-qubit re-layouts (7/8 of a shard to seven peers) through the fused path."""
-    _run(8, 10, [(True, "belady"), (False, "heuristic")])
+    _run(8, 10, [(True, "belady"), (False, "heuristic")], expect_home_moves=True)
 
 
 def test_two_local_qubits_is_the_minimum():

@@ -99,12 +99,54 @@ def test_pass_counts_prove_the_fusion():
         passes = state.apply_ops_io(ops, src=(buf2, bits), dst=(buf0, bits, buf1 if own >= 0 else None, own))
         assert passes == plain_passes, (m, own, passes, plain_passes)
         with pytest.raises(ValueError, match="source buffer must differ"):
-            state.apply_ops_io(ops, src=(buf1, bits), dst=(buf0, bits, buf1, max(own, 0)))
+            state.apply_ops_io(ops, src=(buf0, bits), dst=(buf0, bits, buf1, max(own, 0)))
         slab = 1 << (k - m)
         g0, g1 = buf0.download(), buf1.download()
         for d, w in enumerate(_slabs(want, bits)):
             np.testing.assert_allclose((g1 if d == own else g0)[d * slab:(d + 1) * slab], w, rtol=0, atol=1e-11, err_msg=f"m={m} slab {d}")
     for c in (state, buf0, buf1, buf2):
+        c.close()
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_three_buffers_own_slab_in_the_source_buffer_or_in_the_chunk(split):
+    """dst_own == src (a rank then holds three shard-sized buffers, not four): with two or more kernels the own slab lands
+    in the consumed source buffer; when ONE pass reads the source and stores the slabs it lands in the chunk itself and
+    qsim_apply_ops_io_own_slab says so.  Whole and split forms (pieces stored / announced in random order)."""
+    from quantum_simulations_amd.kernel.device import DeviceChunk
+    k = 20
+    rng = np.random.default_rng(77 + split)
+    state, buf0, buf1 = DeviceChunk.empty(k), DeviceChunk.empty(k), DeviceChunk.empty(k)
+    seen = set()
+    for case, (m_in, m_out, n_ops) in enumerate(((2, 2, 120), (2, 1, 3), (1, 3, 4), (3, 2, 90), (1, 1, 0), (2, 2, 1))):
+        bits_in = [int(b) for b in rng.choice(np.arange(3, k), size=m_in, replace=False)]
+        bits_out = list(range(k - m_out, k))[::-1]            # (at the top: never tile bits of a pass on the qubits below)
+        own = int(rng.integers(0, 1 << m_out))
+        ops = _random_ops(k - 3, n_ops, 9100 + case) if n_ops else []
+        psi0 = _rand_state(k, 9200 + case)
+        want = psi0.copy()
+        orc.apply_ops(want, ops)
+        buf1.upload(np.concatenate(_slabs(psi0, bits_in)))
+        buf0.init_zero(False)
+        state.init_zero(False)
+        passes = state.apply_ops_io(ops, src=(buf1, bits_in), dst=(buf0, bits_out, buf1, own),
+                                    parts=-4 if split else 0, src_parts=-4 if split else 0)
+        if split:
+            n_src = state.source_parts()[0]
+            for j in rng.permutation(n_src):
+                state.load_part(int(j))
+            for j in rng.permutation(len(state.pending_parts())):
+                state.store_part(int(j))
+        in_chunk = state.own_slab_in_chunk()
+        assert in_chunk == (passes == 1), (case, passes, in_chunk)
+        seen.add(in_chunk)
+        slab = 1 << (k - m_out)
+        g0, g1 = buf0.download(), (state if in_chunk else buf1).download()
+        for d, w in enumerate(_slabs(want, bits_out)):
+            np.testing.assert_allclose((g1 if d == own else g0)[d * slab:(d + 1) * slab], w, rtol=0, atol=1e-11,
+                                       err_msg=f"case {case}: {bits_in} -> {bits_out}, own {own} (in chunk: {in_chunk}), slab {d}")
+    assert seen == {False, True}
+    for c in (state, buf0, buf1):
         c.close()
 
 
