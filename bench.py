@@ -366,6 +366,17 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
     invalid: list[str] = []
     p = world.bit_length() - 1
     n = k + p
+    if rank == 0:
+        # a line a minute on stderr while the ranks work (the one-device reference runs of 2^33 amplitudes take a while; a
+        # silent job looks hung to whoever watches it)
+        import threading
+        t_start = time.time()
+
+        def heartbeat():
+            while True:
+                time.sleep(60)
+                print(f"bench.py: {time.time() - t_start:.0f} s, {world} ranks at work", file=sys.stderr, flush=True)
+        threading.Thread(target=heartbeat, daemon=True).start()
     circuit = gen.random_1q_cx_circuit(n, depth=args.depth)
     n_gates = len(circuit["gates"])
     engine = make_engine(n, world, rank, local_rank, mode=args.mode, rehearsal=args.rehearsal, exchange=args.exchange)
