@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _worker(rank, world, port, n, errors):
+def _worker(rank, world, port, n, errors, moves):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                           RANK=str(rank), WORLD_SIZE=str(world))
@@ -28,13 +28,21 @@ def _worker(rank, world, port, n, errors):
         for staging in (True, False):
             eng = DistributedEngine(n, world, rank, backend=HipShardBackend(n - p, 0), staging=staging,
                                     relayout_pieces=4 if world == 2 else 2, min_piece_qubits=1)
-            for name, cd in _circuits(n).items():
+            circuits = dict(_circuits(n))
+            # dense gates on the global qubits in turn with ONE local gate between them: unstaged, every one is a swap-and-stay
+            # re-layout whose queued op list (the gate itself, now local) reads the receive buffer and stores the next slabs
+            # in one pass -- the own slab goes into "state" and the buffers trade names (three buffers per rank)
+            circuits["pingpong"] = {"number_of_qubits": n, "gates": [g for r in range(3) for g in (
+                {"qubits": [n - 1], "gate": "H"}, {"qubits": [n - 2], "gate": "RY", "params": {"theta": 0.3 + r}},
+                {"qubits": [n - 1, 4], "gate": "CNOT"})]}
+            for name, cd in circuits.items():
                 want = orc.simulate(validate_circuit_dict(cd))
                 eng.init_zero_state()
                 eng.execute(eng.plan(cd))
                 err = float(np.max(np.abs(eng.state_vector() - want)))
                 assert err < 1e-10, f"{name} staging={staging} world={world}: {err}"
                 assert abs(eng.norm2() - 1.0) < 1e-12
+            moves.put((staging, eng.home_moves))
             eng.backend.close()
         eng.close()
     except Exception:
@@ -45,9 +53,9 @@ def _worker(rank, world, port, n, errors):
 @pytest.mark.parametrize("world,n", [(2, 10), (4, 11)])
 def test_ranks_sharing_one_gpu(world, n):
     ctx = mp.get_context("spawn")
-    errors = ctx.SimpleQueue()
+    errors, moves = ctx.SimpleQueue(), ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, errors)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, errors, moves)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -60,3 +68,7 @@ def test_ranks_sharing_one_gpu(world, n):
             p.terminate()
             msgs.append((-1, "timeout"))
     assert not msgs and all(p.exitcode == 0 for p in procs), "\n".join(f"[rank {r}] {m}" for r, m in msgs)
+    total = 0
+    while not moves.empty():
+        total += moves.get()[1]
+    assert world < 4 or total > 0, "no fused re-layout took the one-pass branch (own slab into the chunk, state / buf1 trade names)"
