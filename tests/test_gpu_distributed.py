@@ -50,7 +50,7 @@ def _worker(rank, world, port, n, errors, moves):
         raise
 
 
-@pytest.mark.parametrize("world,n", [(2, 10), (4, 11)])
+@pytest.mark.parametrize("world,n", [(2, 10), (4, 11), (4, 16)])
 def test_ranks_sharing_one_gpu(world, n):
     ctx = mp.get_context("spawn")
     errors, moves = ctx.SimpleQueue(), ctx.SimpleQueue()
@@ -71,4 +71,4 @@ def test_ranks_sharing_one_gpu(world, n):
     total = 0
     while not moves.empty():
         total += moves.get()[1]
-    assert world < 4 or total > 0, "no fused re-layout took the one-pass branch (own slab into the chunk, state / buf1 trade names)"
+    assert n < 16 or total > 0, "no fused re-layout took the one-pass branch (own slab into the chunk, state / buf1 trade names)"
