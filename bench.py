@@ -382,6 +382,7 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
     engine = make_engine(n, world, rank, local_rank, mode=args.mode, rehearsal=args.rehearsal, exchange=args.exchange)
     engine.init_zero_state()
     plan = engine.plan(circuit, repeats=args.warmup + args.steps)
+    layout_info = getattr(engine, "layout_info", None)
     for _ in range(args.warmup):
         engine.execute(plan)
     engine.barrier()
@@ -478,6 +479,9 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
                                f"{n_gates} gates, complex128, {k} local qubits per GPU, shards = high qubits",
                    "n_qubits": n, "local_qubits": k, "gates_per_step": n_gates, "mode": args.mode,
                    "hbm_passes_per_step": passes,
+                   # the initial qubit layout of the partition (|0..0> is the same state under all of them): the identity
+                   # or a random assignment, whichever gives the staged schedule fewer passes + re-layouts (model weights)
+                   "qubit_layout": layout_info,
                    "unit_note": "value = gates of the circuit applied to the WHOLE 2^n state per second (the same "
                                 "unit at every N; per-GPU shard work is fixed, so this is weak scaling)"},
         "timed_seconds": round(dt, 4),

@@ -299,7 +299,7 @@ class DistributedEngine:
                  mode: str = "fused", backend=None, staging: bool = True,
                  staging_method: str = "belady", init_process_group: bool = True,
                  relayout_pieces: int = 4, min_piece_qubits: int = 20, fuse_relayout: bool = True,
-                 rehearsal: bool = False, exchange: str = "torch"):
+                 rehearsal: bool = False, exchange: str = "torch", layout: str = "auto"):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -352,6 +352,16 @@ class DistributedEngine:
         if relayout_pieces not in (1, 2, 4, 8):
             raise ValueError("relayout_pieces must be 1, 2, 4 or 8")
         self.relayout_pieces, self.min_piece_qubits = relayout_pieces, min_piece_qubits
+        # Initial qubit layout (round 4): |0..0> is the same state under every assignment of qubits to index bits, so the first
+        # plan after `init_zero_state` may start from any -- which qubits are global first, which three sit on the line bits
+        # (they belong to every tile) -- and the staged schedule that follows differs in re-layouts and HBM passes:
+        # `plan` tries LAYOUT_CANDIDATES random assignments beside the identity and keeps the cheapest (`_schedule_cost`).
+        # "auto": staged runs with shards of >= 20 local qubits; "search": always (tests); "identity": never.
+        if layout not in ("auto", "search", "identity"):
+            raise ValueError("layout must be 'auto', 'search' or 'identity'")
+        self.layout = layout
+        self._fresh = False                        # the state is |0..0> and no plan has chosen a layout for it yet
+        self.layout_info = None
         self._passes = self.last_passes = 0
         self.home_moves = 0                        # times "state" and "buf1" traded names (one-pass op list between two re-layouts)
         self._pending: list = []
@@ -453,6 +463,7 @@ class DistributedEngine:
     # (program order is kept: they sit between two local batches), or are flushed before anything
     # that reads the shard (an exchange, a re-layout, a reduction, a download).
     def _queue_local(self, op) -> None:
+        self._fresh = False
         self._pending.append(op)
 
     def _run_local(self, ops, dst=None, parts: int = 0) -> None:
@@ -505,6 +516,8 @@ class DistributedEngine:
         self.backend.init_zero(self.rank == 0)
         self.l2p_planned = list(range(self.n))
         self._dyn = list(range(self.n))
+        self._fresh = True
+        self.layout_info = None
 
     def norm2(self) -> float:
         self._flush_local()
@@ -539,10 +552,85 @@ class DistributedEngine:
             steps, moved = batch_levels(levelize(relabeled), self.k), list(range(self.n))
         return steps, [moved[l2p[q]] for q in range(self.n)]
 
+    # ---- the initial layout ---------------------------------------------------------------------
+    LAYOUT_CANDIDATES = 48
+    # An all-to-all over m bits in units of one fused pass of the shard: (2^-m of the shard to each of 2^m - 1 peers, each
+    # over its own xGMI link at 0.8 x 153 GB/s) / (the shard read and written once at 5 TB/s).  A MODEL -- no multi-GPU
+    # node was available to measure it -- used only to weigh re-layouts against passes when two layouts differ in both.
+    RELAYOUT_PASSES = {1: 10.4, 2: 5.2, 3: 2.6}
+
+    def _schedule_cost(self, steps: list) -> tuple:
+        """(cost in pass units, HBM passes of the local op lists, re-layout sizes) of a planned execution: the passes the
+        library's pass builder needs for every step's local ops (qsim_plan_ops: host only, rank independent) and the
+        all-to-all re-layouts its planned cross SWAPs merge into (`run_step`'s grouping: up to three disjoint pairs)."""
+        import ctypes as C
+
+        from quantum_simulations_amd import _lib
+        from quantum_simulations_amd.kernel.device import pack_ops
+        lib = _lib.load()
+        passes, groups = 0, []
+        for step in steps:
+            ops = list(step["local_ops"])
+            if ops and 8 <= self.k <= 35:
+                nq, qubits, mats = pack_ops(ops)
+                count = C.c_int32()
+                _lib.check(lib.qsim_plan_ops(self.k, len(nq), nq.ctypes.data_as(C.c_void_p), qubits.ctypes.data_as(C.c_void_p),
+                                             mats.ctypes.data_as(C.c_void_p), None, 0, C.byref(count)))
+                passes += count.value
+            else:
+                passes += len(ops)                   # (shards too small for tile passes: one launch per gate)
+            group, used = 0, set()
+
+            def close_group():
+                # a re-layout whose local bits lie inside a 128-byte line cannot ride in the neighbouring tile passes: a pack
+                # and an unpack pass of the shard (`relayout`, unfused branch)
+                nonlocal passes
+                groups.append(group)
+                if self.fuse_relayout and min(used) < 3:
+                    passes += 2
+            for op in step["nonlocal_ops"]:
+                qs = list(op[0])
+                if self._is_planned_swap(op) and self._is_cross(qs):
+                    if not (group < 3 and used.isdisjoint(qs)):
+                        close_group()
+                        group, used = 0, set()
+                    group += 1
+                    used.update(qs)
+                elif group:
+                    close_group()
+                    group, used = 0, set()
+            if group:
+                close_group()
+        return passes + sum(self.RELAYOUT_PASSES[m] for m in groups), passes, groups
+
+    def choose_initial_layout(self, cd: dict, n_candidates: int | None = None, seed: int = 20260504) -> list:
+        """l2p for a state that is still |0..0>: the identity or one of `n_candidates` random assignments, whichever gives
+        the staged schedule of `cd` the lowest `_schedule_cost` (ties: the earlier candidate, the identity first).  Every
+        rank computes the same list (same inputs, same code); rank 0's is broadcast and used."""
+        n_candidates = self.LAYOUT_CANDIDATES if n_candidates is None else n_candidates
+        rng = np.random.default_rng(seed)
+        cands = [list(range(self.n))] + [[int(x) for x in rng.permutation(self.n)] for _ in range(n_candidates)]
+        scored = []
+        for l2p in cands:
+            steps, _ = self._steps_from(cd, l2p)
+            scored.append(self._schedule_cost(steps))
+        best = min(range(len(cands)), key=lambda i: (scored[i][0], i))
+        box = [cands[best], {"candidates": len(cands), "identity": {"cost": scored[0][0], "passes": scored[0][1], "relayouts": scored[0][2]},
+                             "chosen": {"cost": scored[best][0], "passes": scored[best][1], "relayouts": scored[best][2], "index": best}}]
+        if self.dist.is_initialized() and self.world > 1:
+            self.dist.broadcast_object_list(box, src=0)
+        self.layout_info = box[1]
+        return box[0]
+
     def plan(self, circuit_dict: dict, repeats: int = 1) -> Plan:
         cd = validate_circuit_dict(circuit_dict)
         if cd["number_of_qubits"] != self.n:
             raise ValueError(f"circuit has {cd['number_of_qubits']} qubits, engine has {self.n}")
+        if self._fresh:
+            # (once per initialised state: a second plan made before the first one runs keeps this layout, so both stay valid)
+            self._fresh = False
+            if self.staging and self.world > 1 and self.k >= 2 and (self.layout == "search" or (self.layout == "auto" and self.k >= 20)):
+                self.l2p_planned = self.choose_initial_layout(cd)
         executions, mappings, starts = [], [], []
         l2p = list(self.l2p_planned)
         for _ in range(max(1, repeats)):
@@ -585,6 +673,7 @@ class DistributedEngine:
         """Ops carry PLANNED physical bits; swap-and-stay moves may have put a planned-local qubit on a
         rank bit (and back), so every op is classified by where its qubits actually are."""
         k = self.k
+        self._fresh = False              # (the state is no longer |0..0>: no later plan may pick another layout for it)
         batch = []
         for qs, U in step["local_ops"]:
             aq = self._actual(qs)
@@ -643,6 +732,7 @@ class DistributedEngine:
         grouped exchange of whole slabs, the next local pass loads them -- no pass of the shard outside the links.
         Unfused: pack / exchange / unpack, pipelined in `pieces` sub-ranges of every slab (while piece s is on the
         links, piece s+1 is being packed and piece s-1 unpacked)."""
+        self._fresh = False
         loc = [min(p) for p in pairs]
         glo = [max(p) for p in pairs]
         m = len(pairs)
@@ -726,6 +816,7 @@ class DistributedEngine:
     def apply_nonlocal(self, qs, U) -> None:
         """qs: ACTUAL physical bits, at least one >= k."""
         k = self.k
+        self._fresh = False
         if len(qs) == 1:
             q = qs[0]
             b = self._rank_bit(q)
@@ -922,7 +1013,7 @@ class DistributedEngine:
         for kind, cd in (("ghz", gen.generate_ghz_circuit(n)), ("ghz_qft", gen.generate_ghz_qft(n))):
             dt, steps = self._timed_circuit(cd)
             err = self.closed_form_error(kind)
-            out["config5"].append({"circuit": kind, "n_qubits": n, "n_gpus": self.world, "gates": len(cd["gates"]),
+            out["config5"].append({"circuit": kind, "n_qubits": n, "n_gpus": self.world, "gates": len(cd["gates"]), "layout": self.layout_info,
                                    "seconds": round(dt, 4), "gate_apps_per_s": round(len(cd["gates"]) / dt, 1),
                                    "steps": steps, "max_abs_err_vs_closed_form": err, "pass_1e-10": bool(err < 1e-10),
                                    "norm2": self.norm2(), "xgmi": self.comm_stats()})
@@ -936,7 +1027,8 @@ class DistributedEngine:
                 self.staging = staging
                 dt, steps = self._timed_circuit(cd)
                 rec[label] = {"seconds": round(dt, 4), "gate_apps_per_s": round(len(cd["gates"]) / dt, 1), "steps": steps,
-                              "hbm_passes": self.last_passes, "norm2": self.norm2(), "xgmi": self.comm_stats()}
+                              "hbm_passes": self.last_passes, "norm2": self.norm2(), "xgmi": self.comm_stats(),
+                              "layout": self.layout_info if staging else None}
                 runs.append((self.fingerprints(seed), self.shard_selectors()))
             self.staging = saved
             if check_amplitudes:

@@ -65,7 +65,8 @@ def _worker(rank, world, port, n, staging_modes, errors, moves=None):
             # neighbouring local passes (the default) or as separate pack / unpack passes
             eng = DistributedEngine(n, world, rank, backend=CpuShardBackend(n - p),
                                     staging=staging, staging_method=method, fuse_relayout=not rest or rest[0],
-                                    relayout_pieces=(4, 2, 1)[mode_no % 3], min_piece_qubits=1)
+                                    relayout_pieces=(4, 2, 1)[mode_no % 3], min_piece_qubits=1,
+                                    layout="search" if mode_no % 2 == 0 else "identity")
             for name, cd in _circuits(n).items():
                 want = orc.simulate(validate_circuit_dict(cd))
                 eng.init_zero_state()
