@@ -361,6 +361,8 @@ class DistributedEngine:
             raise ValueError("layout must be 'auto', 'search' or 'identity'")
         self.layout = layout
         self._fresh = False                        # the state is |0..0> and no plan has chosen a layout for it yet
+        self._model_ref = None                     # (cost model: the average pass over random tiles, set on first use)
+        self._plan_images = np.zeros((64, 4096), dtype=np.uint8)
         self.layout_info = None
         self._passes = self.last_passes = 0
         self.home_moves = 0                        # times "state" and "buf1" traded names (one-pass op list between two re-layouts)
@@ -567,41 +569,54 @@ class DistributedEngine:
 
         from quantum_simulations_amd import _lib
         from quantum_simulations_amd.kernel.device import pack_ops
+        from quantum_simulations_amd.runner import tile_layout
         lib = _lib.load()
-        passes, groups = 0, []
+        # Shards of 26 local qubits and more: a pass is priced by the DRAM pattern of its tile's index bits (the one-GPU
+        # engine's model, runner/tile_layout.py, in units of the model's average pass over random tiles), not counted as
+        # 1: two layouts with the same number of passes differ by a few percent in what the passes cost.
+        model = tile_layout.model_for(self.k) if self.k >= 26 else None
+        if model is not None and self._model_ref is None:
+            rng = np.random.default_rng(7)
+            top = min(self.k - 1, model["top"])
+            self._model_ref = float(np.mean([tile_layout.tile_cost(model, rng.choice(np.arange(3, top + 1), size=8, replace=False))
+                                             for _ in range(256)]))
+        passes, weight, extra, groups = 0, 0.0, 0, []
         for step in steps:
             ops = list(step["local_ops"])
             if ops and 8 <= self.k <= 35:
                 nq, qubits, mats = pack_ops(ops)
                 count = C.c_int32()
-                _lib.check(lib.qsim_plan_ops(self.k, len(nq), nq.ctypes.data_as(C.c_void_p), qubits.ctypes.data_as(C.c_void_p),
-                                             mats.ctypes.data_as(C.c_void_p), None, 0, C.byref(count)))
+                args = (self.k, len(nq), nq.ctypes.data_as(C.c_void_p), qubits.ctypes.data_as(C.c_void_p), mats.ctypes.data_as(C.c_void_p))
+                if model is None:
+                    _lib.check(lib.qsim_plan_ops(*args, None, 0, C.byref(count)))
+                    weight += count.value
+                else:
+                    images = self._plan_images
+                    _lib.check(lib.qsim_plan_ops(*args, images.ctypes.data_as(C.c_void_p), images.nbytes, C.byref(count)))
+                    if count.value > len(images):    # (a buffer too small only reports the count)
+                        images = self._plan_images = np.zeros((2 * count.value, 4096), dtype=np.uint8)
+                        _lib.check(lib.qsim_plan_ops(*args, images.ctypes.data_as(C.c_void_p), images.nbytes, C.byref(count)))
+                    for p in range(count.value):     # (pass image = the kernel-argument block: T at byte 12, the tile's high bits from 16)
+                        T = int(images[p, 12:16].view("<i4")[0])
+                        weight += tile_layout.tile_cost(model, [int(b) for b in images[p, 16:16 + T - 3]]) / self._model_ref
                 passes += count.value
             else:
                 passes += len(ops)                   # (shards too small for tile passes: one launch per gate)
+                weight += len(ops)
             group, used = 0, set()
-
-            def close_group():
-                # a re-layout whose local bits lie inside a 128-byte line cannot ride in the neighbouring tile passes: a pack
-                # and an unpack pass of the shard (`relayout`, unfused branch)
-                nonlocal passes
-                groups.append(group)
-                if self.fuse_relayout and min(used) < 3:
-                    passes += 2
-            for op in step["nonlocal_ops"]:
-                qs = list(op[0])
-                if self._is_planned_swap(op) and self._is_cross(qs):
-                    if not (group < 3 and used.isdisjoint(qs)):
-                        close_group()
-                        group, used = 0, set()
-                    group += 1
-                    used.update(qs)
-                elif group:
-                    close_group()
+            for op in list(step["nonlocal_ops"]) + [None]:
+                cross = op is not None and self._is_planned_swap(op) and self._is_cross(list(op[0]))
+                if group and not (cross and group < 3 and used.isdisjoint(op[0])):
+                    # the group is complete: one re-layout.  With local bits inside a 128-byte line it cannot ride in the
+                    # neighbouring tile passes: a pack and an unpack pass of the shard (`relayout`, unfused branch)
+                    groups.append(group)
+                    if self.fuse_relayout and min(used) < 3:
+                        extra += 2
                     group, used = 0, set()
-            if group:
-                close_group()
-        return passes + sum(self.RELAYOUT_PASSES[m] for m in groups), passes, groups
+                if cross:
+                    group += 1
+                    used.update(op[0])
+        return weight + extra + sum(self.RELAYOUT_PASSES[m] for m in groups), passes + extra, groups
 
     def choose_initial_layout(self, cd: dict, n_candidates: int | None = None, seed: int = 20260504) -> list:
         """l2p for a state that is still |0..0>: the identity or one of `n_candidates` random assignments, whichever gives
@@ -615,8 +630,9 @@ class DistributedEngine:
             steps, _ = self._steps_from(cd, l2p)
             scored.append(self._schedule_cost(steps))
         best = min(range(len(cands)), key=lambda i: (scored[i][0], i))
-        box = [cands[best], {"candidates": len(cands), "identity": {"cost": scored[0][0], "passes": scored[0][1], "relayouts": scored[0][2]},
-                             "chosen": {"cost": scored[best][0], "passes": scored[best][1], "relayouts": scored[best][2], "index": best}}]
+        box = [cands[best], {"candidates": len(cands),
+                             "identity": {"cost": round(scored[0][0], 2), "passes": scored[0][1], "relayouts": scored[0][2]},
+                             "chosen": {"cost": round(scored[best][0], 2), "passes": scored[best][1], "relayouts": scored[best][2], "index": best}}]
         if self.dist.is_initialized() and self.world > 1:
             self.dist.broadcast_object_list(box, src=0)
         self.layout_info = box[1]

@@ -43,7 +43,7 @@ def test_choice_is_never_dearer_than_the_identity_and_is_reproducible(n, world, 
     assert (info["chosen"]["index"] == 0) == (first == list(range(n)))
     assert eng.choose_initial_layout(cd, n_candidates=12) == first          # same inputs, same answer (every rank computes it)
     steps, _ = eng._steps_from(cd, first)
-    assert eng._schedule_cost(steps)[0] == pytest.approx(info["chosen"]["cost"])
+    assert eng._schedule_cost(steps)[0] == pytest.approx(info["chosen"]["cost"], abs=0.006)
 
 
 def test_only_the_first_plan_of_a_fresh_state_chooses():
