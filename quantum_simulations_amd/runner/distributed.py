@@ -639,6 +639,9 @@ class DistributedEngine:
         return box[0]
 
     def plan(self, circuit_dict: dict, repeats: int = 1) -> Plan:
+        """Step lists for `repeats` successive executions from the engine's current layout.  COLLECTIVE when it is the first
+        plan of a freshly initialised state and the engine searches the initial layout (every rank must call it: rank 0's
+        choice is broadcast); host-only otherwise."""
         cd = validate_circuit_dict(circuit_dict)
         if cd["number_of_qubits"] != self.n:
             raise ValueError(f"circuit has {cd['number_of_qubits']} qubits, engine has {self.n}")
