@@ -20,6 +20,7 @@ rng = np.random.default_rng(2026)
 t0 = time.time()
 cases = 0
 worst = 0.0
+three_in_chunk = three_in_source = 0
 while time.time() - t0 < budget:
     n = int(rng.integers(1, 21))
     seed = int(rng.integers(1 << 30))
@@ -49,7 +50,9 @@ while time.time() - t0 < budget:
         keep.init_zero(False)
         dev.init_zero(False)
         split = int(rng.integers(0, 4))       # 0: one call stores the slabs; else the split form, pieces stored in random order
-        dev.apply_ops_io(ops, src=(src, bits_in), dst=(dst, bits_out, keep if own >= 0 else None, own), parts=-(1 << split) if split else 0)
+        three = own >= 0 and rng.random() < 0.5      # three buffers: the own slab goes into the consumed source buffer -- or,
+        own_buf = src if three else keep             # when one pass does everything, into the chunk itself (own_slab_in_chunk)
+        dev.apply_ops_io(ops, src=(src, bits_in), dst=(dst, bits_out, own_buf if own >= 0 else None, own), parts=-(1 << split) if split else 0)
         if split:
             parts = dev.pending_parts()
             slab_amps = (1 << n) >> m
@@ -59,12 +62,16 @@ while time.time() - t0 < budget:
                 off, cnt = parts[int(j)]
                 seen[off:off + cnt] += 1
             assert np.all(seen == 1), ("pieces do not tile the slab", n, seed, bits_out, parts)
-        g0, g1 = dst.download(), keep.download()
+        in_chunk = dev.own_slab_in_chunk()
+        assert not in_chunk or three, ("own slab in the chunk without being asked", n, seed)
+        three_in_chunk += in_chunk
+        three_in_source += three and not in_chunk
+        g0, g1 = dst.download(), (dev if in_chunk else own_buf).download()
         slab = (1 << n) >> m
         for d, w in enumerate(slabs(want, bits_out)):
             err = float(np.max(np.abs((g1 if d == own else g0)[d * slab:(d + 1) * slab] - w)))
             worst = max(worst, err)
-            assert err < 1e-10, ("io", n, seed, bits_in, bits_out, own, d, err)
+            assert err < 1e-10, ("io", n, seed, bits_in, bits_out, own, d, three, in_chunk, err)
         for c in (src, dst, keep):
             c.close()
     dev.close()
@@ -139,4 +146,5 @@ while time.time() - t1 < budget * 0.5:
     big_cases += 1
     print(f"... large case {big_cases}: n = {n}, {len(ops)} ops, err {err:.2e}; slabs over {bits} in {len(parts)} piece(s), {dev_launches} partial launch(es)", flush=True)
 print(f"stress ok: {big_cases} large cases (21-25 qubits, fused) in {time.time() - t1:.0f} s")
-print(f"stress ok: {cases} random cases in {time.time() - t0:.0f} s, worst |diff| = {worst:.2e}")
+print(f"stress ok: {cases} random cases in {time.time() - t0:.0f} s, worst |diff| = {worst:.2e}; three-buffer re-layout ends: "
+      f"{three_in_source} own slabs into the source buffer, {three_in_chunk} into the chunk")
