@@ -409,6 +409,8 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
         for rec in configs.get("config5", []):
             if not rec["max_abs_err_vs_closed_form"] < PARITY_TOL:
                 invalid.append(f"config 5 {rec['circuit']}: max error {rec['max_abs_err_vs_closed_form']:.3e}")
+            if not rec.get("max_abs_err_sampled_host_check", 0.0) < PARITY_TOL:
+                invalid.append(f"config 5 {rec['circuit']}: sampled host check {rec['max_abs_err_sampled_host_check']:.3e}")
         for key in ("config4", "random_1q_cx"):
             rec = configs.get(key) or {}
             for label in ("staged", "unstaged"):

@@ -67,8 +67,8 @@ class CpuShardBackend:
     def norm2(self) -> float:
         return float(np.vdot(self._c("state"), self._c("state")).real)
 
-    def download(self) -> np.ndarray:
-        return self._c("state").copy()
+    def download(self, offset: int = 0, count: int | None = None) -> np.ndarray:
+        return self._c("state")[offset:None if count is None else offset + count].copy()
 
     def sync(self) -> None:
         pass

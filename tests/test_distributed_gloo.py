@@ -77,6 +77,13 @@ def _worker(rank, world, port, n, staging_modes, errors, moves=None):
                 assert err < 1e-12, f"{name} staging={staging}/{method} world={world}: {err}"
                 if name in ("ghz", "ghz_qft"):   # closed form evaluated shard by shard in the staged layout
                     assert eng.closed_form_error(name) < 1e-12
+                    assert eng.closed_form_sample_error(name, windows=5, window=8) < 1e-12      # ... and the sampled host check
+                    if name == "ghz" and rank == world - 1:      # (a wrong amplitude in a sampled window is seen)
+                        eng.backend._c("state")[-1] += 1e-6
+                    bad = eng.closed_form_sample_error(name, windows=5, window=8) if name == "ghz" else 1.0
+                    assert bad > 5e-7, bad
+                    if name == "ghz" and rank == world - 1:
+                        eng.backend._c("state")[-1] -= 1e-6
                 assert abs(eng.norm2() - 1.0) < 1e-12
                 # second execution continues from the permuted layout: psi2 = C(C|0>)
                 eng.execute(plan)

@@ -26,6 +26,7 @@ def test_four_ranks_sharing_one_gpu_through_the_launcher():
     assert doc["config"]["n_qubits"] == 22 and "invalid" not in doc
     cfg = doc["baseline_configs"]
     assert all(r["pass_1e-10"] for r in cfg["config5"])
+    assert all(r["max_abs_err_sampled_host_check"] < 1e-10 for r in cfg["config5"])      # ("plus sampled host check")
     for key, labels in (("config4", ("staged", "unstaged")), ("random_1q_cx", ("staged",))):
         for label in labels:
             assert cfg[key][label]["fingerprint_max_abs_diff_vs_single_gpu"] < 1e-10

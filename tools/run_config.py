@@ -74,9 +74,11 @@ def main():
             phase[0] = kind
             dt, steps = timed_run(eng, cd)
             err = eng.closed_form_error(kind)
-            out.append({"config": 5, "circuit": kind, "n_qubits": n, "n_gpus": world, "gates": len(cd["gates"]),
+            err_host = eng.closed_form_sample_error(kind)
+            out.append({"config": 5, "circuit": kind, "n_qubits": n, "n_gpus": world, "gates": len(cd["gates"]), "layout": eng.layout_info,
                         "exchange": eng.exchange, "seconds": round(dt, 4), "gate_apps_per_s": round(len(cd["gates"]) / dt, 1),
-                        "steps": steps, "max_abs_err_vs_closed_form": err, "pass_1e-10": bool(err < 1e-10),
+                        "steps": steps, "max_abs_err_vs_closed_form": err, "max_abs_err_sampled_host_check": err_host,
+                        "pass_1e-10": bool(err < 1e-10 and err_host < 1e-10),
                         "norm2": eng.norm2(), "xgmi": eng.comm_stats()})
     else:
         cd = gen.random_clifford_t_circuit(n, depth=60)
