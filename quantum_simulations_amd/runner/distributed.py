@@ -1074,8 +1074,14 @@ class DistributedEngine:
             for label, staging in variants:
                 self.staging = staging
                 dt, steps = self._timed_circuit(cd)
+                stats = self.comm_stats()
+                ms = stats.get("exchange_ms_max_over_ranks")
                 rec[label] = {"seconds": round(dt, 4), "gate_apps_per_s": round(len(cd["gates"]) / dt, 1), "steps": steps,
-                              "hbm_passes": self.last_passes, "norm2": self.norm2(), "xgmi": self.comm_stats(),
+                              "hbm_passes": self.last_passes, "norm2": self.norm2(), "xgmi": stats,
+                              # device-side exchange time (stream events, max over ranks; RCCL runs
+                              # only) over the run's wall time -- pieces overlap compute, so this is an upper bound of
+                              # what the links cost
+                              "exchange_time_share": (round(ms * 1e-3 / dt, 4) if ms is not None else None),
                               "layout": self.layout_info if staging else None}
                 runs.append((self.fingerprints(seed), self.shard_selectors()))
             self.staging = saved
