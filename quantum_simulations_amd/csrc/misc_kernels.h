@@ -359,6 +359,86 @@ __global__ __launch_bounds__(kBlock) void k_dense(const DenseArgs a) {
   }
 }
 
+// Dense 3- and 4-qubit blocks on the MATRIX cores (round 4): a genuine 2^K x 2^K complex contraction per block of 2^K
+// amplitudes = a real 2^(K+1) x 2^(K+1) matrix [[Re, -Im], [Im, Re]] (rows / columns 2 p + c: pattern p, c = 0 real / 1
+// imaginary -- the order the amplitudes lie in memory) times the 2^(K+1) reals of the block, as v_mfma_f64_16x16x4_f64: a
+// wave takes 16 COLUMNS (= 16 blocks: consecutive values of the index bits that are not block bits) at a time; K = 4: two
+// 16-row output tiles x eight k-steps = 16 MFMAs per 256 amplitudes (128 flop per amplitude: 1.75 ms of the matrix cores'
+// 78 Tflop/s at 30 qubits, under the 4.3 ms of HBM); K = 3: one tile x four k-steps per 128 amplitudes.  Operand layouts
+// (lane l: j = l & 15, g = l >> 4; measured with tools/mfma_probe.hip in round 2):
+//   A of k-step s, row tile t:  Mr[16 t + j][4 s + g]            (formed once per wave from the caller's complex matrix)
+//   B of k-step s:              X[row 4 s + g][column j]  = component g & 1 of pattern 2 s + (g >> 1) of block j
+//   D element i of row tile t:  Y[row 16 t + 4 i + g][column j] = component g & 1 of pattern 2 (4 t + i) + (g >> 1)
+// so a lane reads the doubles { pattern 2 m + (g >> 1), m = 0 .. 2^(K-1) - 1 } x { component g & 1 } of its block and writes
+// its results back to the same places: in place, no shuffles, no LDS.  Lane pairs (g & 1) cover one amplitude (16 B), 32
+// lanes 256 contiguous bytes when the block bits lie above index bit 3.  Measured at 30 qubits (profiles/r04x_*): K = 4
+// 0.68-0.73 of the HBM peak against 0.43 for the vector-ALU form (k_dense<4>: 256 complex multiply-adds per work item at 128+
+// VGPRs) -- the one place of this path where the work IS a matrix product (north star: "MFMA only for fused
+// multi-qubit dense blocks where it is a real 2^k x 2^k contraction").
+struct DenseMfmaArgs {
+  double* amp;              // the chunk as reals
+  const double2* mat;       // the caller's 2^K x 2^K complex matrix, row-major M[out][in] (its real image is formed in registers)
+  u64 col_blocks;           // groups of 16 columns: 2^(k - K - 4)
+  int pos[4];               // the block's index bits, ascending (zeros are inserted there)
+  int bit[4];               // pattern bit i <-> index bit bit[i] (the caller's qubit order)
+};
+constexpr int kDenseMfmaColBlocksPerWave = 4;
+typedef double qs_double4_t __attribute__((ext_vector_type(4)));
+template <int K, bool NT>
+__global__ __launch_bounds__(kBlock) void k_dense_mfma(const DenseMfmaArgs a) {
+  static_assert(K == 3 || K == 4, "16-row MFMA tiles: 16 or 32 reals per block");
+  constexpr int TT = 1 << (K - 3);          // 16-row output tiles
+  constexpr int S = 1 << (K - 1);           // k-steps of 4 rows = patterns per lane
+  constexpr int DIM = 1 << K;
+  const int l = threadIdx.x & 63, j = l & 15, g = l >> 4;
+  double A[TT][S];
+#pragma unroll
+  for (int t = 0; t < TT; ++t)
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      // Mr[2 po + co][2 pi + ci] = Re M[po][pi] if co == ci, Im if (co, ci) = (1, 0), -Im if (0, 1)
+      const int r = 16 * t + j, col = 4 * s + g;
+      const double2 z = a.mat[(r >> 1) * DIM + (col >> 1)];
+      A[t][s] = (r & 1) == (col & 1) ? z.x : ((r & 1) ? z.y : -z.y);
+    }
+  u64 off[S];               // (wave-uniform) offsets of the patterns' upper K - 1 bits, in reals
+#pragma unroll
+  for (int m = 0; m < S; ++m) {
+    u64 o = 0;
+#pragma unroll
+    for (int i = 0; i < K - 1; ++i) o |= (u64)((m >> i) & 1) << a.bit[i + 1];
+    off[m] = 2 * o;
+  }
+  const u64 lane_part = 2 * ((u64)(g >> 1) << a.bit[0]) + (u64)(g & 1);
+  const u64 wave = logical_block<true>() * (kBlock / 64) + (threadIdx.x >> 6);
+#pragma unroll
+  for (int it = 0; it < kDenseMfmaColBlocksPerWave; ++it) {
+    const u64 cb = wave * kDenseMfmaColBlocksPerWave + it;
+    if (cb >= a.col_blocks) break;                    // (wave-uniform)
+    u64 c = cb * 16 + (u64)j;
+#pragma unroll
+    for (int i = 0; i < K; ++i) { const int p = a.pos[i]; c = ((c >> p) << (p + 1)) | (c & ((1ull << p) - 1)); }
+    double* const p0 = a.amp + 2 * c + lane_part;
+    double x[S];
+#pragma unroll
+    for (int m = 0; m < S; ++m) x[m] = NT ? __builtin_nontemporal_load(p0 + off[m]) : p0[off[m]];
+    qs_double4_t acc[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) acc[t] = qs_double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int t = 0; t < TT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t][s], x[s], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (NT) __builtin_nontemporal_store(acc[t][i], p0 + off[4 * t + i]);
+        else p0[off[4 * t + i]] = acc[t][i];
+      }
+  }
+}
+
 static int ensure_scratch(qsim_chunk* c) {
   if (!c->scratch) {
     HIP_TRY(hipSetDevice(c->device));

@@ -388,6 +388,28 @@ int qsim_apply_fused_k(qsim_chunk* c, int k, const int32_t* qubits, const double
   std::sort(sorted, sorted + k);
   for (int i = 0; i < 4; ++i) a.pos[i] = sorted[i];
   const bool nt = c->span_bytes > tuning().mall_bytes && sorted[0] >= kLaneCut;
+  if (c->k >= k + 4 && ((tuning().dense_mfma >> (k - 3)) & 1)) {
+    // the matrix-core form (misc_kernels.h k_dense_mfma): 16 columns per wave and step
+    DenseMfmaArgs d;
+    d.amp = reinterpret_cast<double*>(c->amp);
+    d.mat = a.mat;
+    d.col_blocks = amps(c) >> (k + 4);
+    for (int i = 0; i < 4; ++i) { d.pos[i] = sorted[i]; d.bit[i] = i < k ? qubits[i] : 0; }
+    const u64 waves = (d.col_blocks + kDenseMfmaColBlocksPerWave - 1) / kDenseMfmaColBlocksPerWave;
+    u64 wgs = (waves + kBlock / 64 - 1) / (kBlock / 64);
+    wgs = (wgs + 7) & ~7ull;
+    ProfileScope prof(7, 32.0 * (double)amps(c), c->stream, nt);
+    if (k == 3) {
+      if (nt) hipLaunchKernelGGL((k_dense_mfma<3, true>), grid_for(wgs), dim3(kBlock), 0, c->stream, d);
+      else hipLaunchKernelGGL((k_dense_mfma<3, false>), grid_for(wgs), dim3(kBlock), 0, c->stream, d);
+    } else {
+      if (nt) hipLaunchKernelGGL((k_dense_mfma<4, true>), grid_for(wgs), dim3(kBlock), 0, c->stream, d);
+      else hipLaunchKernelGGL((k_dense_mfma<4, false>), grid_for(wgs), dim3(kBlock), 0, c->stream, d);
+    }
+    prof.done(c->stream);
+    HIP_TRY(hipGetLastError());
+    return QSIM_OK;
+  }
   u64 blocks = (a.count + kBlock - 1) / kBlock;
   blocks = (blocks + 7) & ~7ull;                     // whole octets: logical_block<true> deals blocks over the 8 XCDs
   ProfileScope prof(7, 32.0 * (double)amps(c), c->stream, nt);
