@@ -112,6 +112,44 @@ def test_config3_every_target_amplitudes_30q(hip):
     dev.close()
 
 
+def test_dense_blocks_on_the_matrix_cores_at_30_qubits(hip):
+    """qsim_apply_fused_k at full size (k_dense_mfma: 16 GiB, the streaming instantiation, real offsets beyond 2^32): dense
+    random unitaries on 3 and 4 qubits -- low, high, mixed and line bits, in the caller's (unsorted) order -- against the
+    same contraction on the host for sampled blocks (every sampled amplitude has its 2^k - 1 partners sampled)."""
+    n = 30
+    dev = hip.DeviceChunk.empty(n)
+    dev.init_random(31)
+    rng = np.random.default_rng(3131)
+    run_len = 64
+    for qubits in ([29, 3, 17], [28, 29, 27], [5, 4, 3, 6], [29, 26, 27, 28], [12, 29, 4, 20], [1, 25, 0, 9]):
+        k = len(qubits)
+        M = np.linalg.qr(rng.standard_normal((1 << k, 1 << k)) + 1j * rng.standard_normal((1 << k, 1 << k)))[0]
+        groups = _sample_runs(n, qubits, rng, runs=24)
+        before = _download_sample(dev, groups)
+        want = {b: v.copy() for b, v in before.items()}
+        done = set()
+        for b0 in before:
+            for j in range(run_len):
+                base = b0 + j
+                for q in qubits:
+                    base &= ~(1 << q)
+                if base in done:
+                    continue
+                done.add(base)
+                idx = [base | sum(((pat >> i) & 1) << q for i, q in enumerate(qubits)) for pat in range(1 << k)]
+                vec = np.array([before[i & ~(run_len - 1)][i & (run_len - 1)] for i in idx])
+                for i, r in zip(idx, M @ vec):
+                    want[i & ~(run_len - 1)][i & (run_len - 1)] = r
+        dev.apply_fused_k(qubits, M)
+        after = _download_sample(dev, groups)
+        err = max(float(np.max(np.abs(after[b] - want[b]))) for b in want)
+        changed = max(float(np.max(np.abs(after[b] - before[b]))) for b in want)
+        assert err < 1e-12, f"dense block on {qubits}: max |device - host| = {err}"
+        assert changed > 1e-9, qubits
+    assert abs(dev.norm2() - 1.0) < 1e-11
+    dev.close()
+
+
 def test_slab_layouts_at_30_qubits_64_bit_offsets(hip):
     """qsim_apply_ops_io at full shard size (30 local qubits, the multi-GPU configuration): slab bits at the top of the
     index push tile bits to physical positions >= 28 (the 64-bit-offset instantiations of k_tile) on both sides.
