@@ -1,8 +1,9 @@
 """Fused application of independent gates, interface of v3's `ParallelGateApplicator`
 (v3_hisvsim_spark/src/parallel_gate_applicator.py:52-126,169-204).
 
-`apply_gates_parallel(state, gates)` applies gates on pairwise different qubits in ONE pass of
-the HBM-resident state (a fused LDS-tile launch) instead of one DataFrame transformation.
+`apply_gates_parallel(state, gates)` applies a level's gates (v3: pairwise different qubits; overlapping ones in list
+order, two-qubit gates last) in ONE pass of the HBM-resident state (a fused LDS-tile launch) instead of one DataFrame
+transformation per gate.
 `tensor_product_single_qubits` builds the 2^k x 2^k matrix M[out, in] = prod_i U_i[out_i, in_i]
 (bit i <-> i-th smallest qubit) that v3 materialises as a coefficient list; the GPU never builds
 it -- k butterflies inside one tile pass cost 14k flop per amplitude instead of 8 * 2^k
@@ -29,14 +30,14 @@ class ParallelGateApplicator:
         self.device = device
 
     def apply_gates_parallel(self, state: DeviceChunk, gates: list[dict]) -> DeviceChunk:
-        """`gates`: normalised gate dicts on pairwise different qubits (one level's group)."""
-        seen: set[int] = set()
-        for g in gates:
-            if seen & set(g["qubits"]):
-                raise ValueError("apply_gates_parallel needs gates on different qubits")
-            seen |= set(g["qubits"])
+        """`gates`: normalised gate dicts of one level's group.  As in v3 (parallel_gate_applicator.py:75-126): the
+        single-qubit gates first -- fused when they act on different qubits, one after the other in list order when two of
+        them share a qubit -- then the two-qubit gates in list order.  Here both cases are ONE call: a fused pass keeps the
+        list order of ops that share a qubit and is free to run the others together."""
+        singles = [g for g in gates if len(g["qubits"]) == 1]
+        doubles = [g for g in gates if len(g["qubits"]) != 1]
         state.apply_ops([(g["qubits"], gate_table.gate_matrix(g["gate"], g.get("params") or {}))
-                         for g in gates])
+                         for g in singles + doubles])
         return state
 
     def apply_combined_matrix(self, state: DeviceChunk, qubits: list[int], M: np.ndarray) -> DeviceChunk:

@@ -60,8 +60,18 @@ def test_gpu_driver_matches_v3_worker_rows():
     state = DeviceChunk.zero_state(10)
     ParallelGateApplicator().apply_gates_parallel(state, levelize(cd)[0])
     np.testing.assert_allclose(state.download(), npz("states.npz")["v1_hadamard_wall_10"], atol=1e-12)
-    with pytest.raises(ValueError, match="different qubits"):
-        ParallelGateApplicator().apply_gates_parallel(state, [{"qubits": [0], "gate": "H"}, {"qubits": [0], "gate": "X"}])
+    # v3's rules for a group that is NOT independent (parallel_gate_applicator.py:99-123): overlapping single-qubit gates one
+    # after the other in list order, two-qubit gates after ALL single-qubit ones
+    from oracle import dense_oracle as orc
+    group = [{"qubits": [0], "gate": "H"}, {"qubits": [1, 0], "gate": "CNOT"}, {"qubits": [0], "gate": "T"}, {"qubits": [3], "gate": "X"},
+             {"qubits": [3, 2], "gate": "CZ"}, {"qubits": [0], "gate": "H"}]
+    before = state.download()
+    want = before.copy()
+    for g in [g for g in group if len(g["qubits"]) == 1] + [g for g in group if len(g["qubits"]) == 2]:
+        U = orc.gate_matrix(g["gate"])
+        (orc.apply_1q if len(g["qubits"]) == 1 else orc.apply_2q)(want, *g["qubits"], U)
+    ParallelGateApplicator().apply_gates_parallel(state, group)
+    np.testing.assert_allclose(state.download(), want, atol=1e-12)
     state.close()
 
 
