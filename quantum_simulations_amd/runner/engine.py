@@ -242,10 +242,23 @@ class SingleGpuEngine:
                 "T(q)": row("T", range(n), lambda q: dev.apply_1q(q, T), 16 * N, subline),
                 "CNOT(q,q+1)": row("CX", range(n - 1), lambda q: dev.apply_2q(q, q + 1, CX), 16 * N, subline),
                 "CNOT(0,q)": row("CX0", range(1, n), lambda q: dev.apply_2q(0, q, CX), 16 * N, subline)}
+        # the one GEMM-shaped op of the path: dense 2^k x 2^k blocks on the matrix cores (qsim_apply_fused_k -> k_dense_mfma),
+        # random unitaries on low / middle / high / mixed index bits above the 128-byte line
+        rng = np.random.default_rng(4)
+        dense = {}
+        for k in (3, 4):
+            sets = [list(range(3, 3 + k)), list(range(10, 10 + k)), list(range(n - k, n)), [5, 14, n - 2] + ([n - 9] if k == 4 else [])]
+            sets = [qs for qs in sets if max(qs) < n and len(set(qs)) == k]
+            M = np.linalg.qr(rng.standard_normal((1 << k, 1 << k)) + 1j * rng.standard_normal((1 << k, 1 << k)))[0]
+            ms = [timed(lambda qs=qs: dev.apply_fused_k(qs, M)) for qs in sets]
+            fr = [32 * N / (t * 1e-3) / 8.0e12 for t in ms]
+            dense[f"k={k}"] = {"qubit_sets": sets, "ms": [round(t, 4) for t in ms], "frac_of_8TBps": [round(f, 4) for f in fr],
+                               "flop_per_amplitude": 8 * (1 << k),
+                               "kernel": f"k_dense_mfma<{k}> (v_mfma_f64_16x16x4_f64, 16 blocks per wave and step, in place)"}
         norm2 = dev.norm2()
         if dev is not self.state:
             dev.close()
-        return {"n_qubits": n, "reps": reps, "rows": rows, "norm2_after": norm2}
+        return {"n_qubits": n, "reps": reps, "rows": rows, "dense_blocks": dense, "norm2_after": norm2}
 
     def copy_ceiling(self, reps: int = 7) -> dict:
         """Same-run device-to-device copy of a buffer of the state's size (qsim_copy: streaming loads and

@@ -40,7 +40,7 @@ def test_single_gpu_line_carries_the_contract_fields():
     kind, sample} -- exit code 0, no `invalid`; and exit code 2 with a QSIM_* knob in the environment."""
     env = {k: v for k, v in os.environ.items()
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE") and not k.startswith("QSIM_")}
-    cmd = [sys.executable, str(ROOT / "bench.py"), "--local-qubits", "22", "--steps", "3", "--warmup", "1", "--no-sweep",
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--local-qubits", "22", "--steps", "3", "--warmup", "1", "--sweep-qubits", "20",
            "--fused-qubits", "0", "--sustain-seconds", "0", "--cpu-seconds", "2"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
@@ -56,5 +56,11 @@ def test_single_gpu_line_carries_the_contract_fields():
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert d["parity_max_abs_diff_vs_cpu_prefix"] < 1e-10 and "invalid" not in d
+    sweep = d["sweep30"]                         # (config 3's section, here at 20 qubits: one launch per gate and target)
+    assert set(sweep["rows"]) == {"H(q)", "T(q)", "CNOT(q,q+1)", "CNOT(0,q)"} and len(sweep["rows"]["H(q)"]["frac_of_8TBps"]) == 20
+    for k in (3, 4):                             # ... and the dense blocks on the matrix cores
+        blocks = sweep["dense_blocks"][f"k={k}"]
+        assert len(blocks["qubit_sets"]) == 4 and all(f > 0 for f in blocks["frac_of_8TBps"]) and "mfma" in blocks["kernel"]
+    assert abs(sweep["norm2_after"] - 1.0) < 1e-10
     bad = subprocess.run(cmd, cwd=ROOT, env=dict(env, QSIM_PLAN_LOOKAHEAD="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode == 2 and "refusing" in bad.stdout
