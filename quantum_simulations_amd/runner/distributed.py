@@ -294,6 +294,85 @@ class DryBackend:
         pass
 
 
+class PlanningBackend(DryBackend):
+    """A dry backend that knows what the library WOULD do with every op list: the HBM passes of `qsim_apply_ops_io` (the host
+    planner `qsim_plan_ops` on exactly the ops a rank runs, plus the pack / unpack passes of ends that cannot ride in a tile
+    pass: slab bits inside a 128-byte line, a slab bit among the tile bits of the last pass, nothing to plan) and, from 26
+    local qubits on, each pass weighted by the tile-cost model's prediction for its tile's index bits (runner/tile_layout.py,
+    in units of the model's average pass).  `DistributedEngine.choose_initial_layout` executes candidate schedules on it."""
+
+    def __init__(self, k: int):
+        super().__init__(k)
+        from quantum_simulations_amd.runner import tile_layout
+        self._tile_layout = tile_layout
+        self.model = tile_layout.model_for(k) if k >= 26 else None
+        self.model_ref = 1.0
+        if self.model is not None:
+            rng = np.random.default_rng(7)
+            top = min(k - 1, self.model["top"])
+            self.model_ref = float(np.mean([tile_layout.tile_cost(self.model, rng.choice(np.arange(3, top + 1), size=8, replace=False))
+                                            for _ in range(256)]))
+        self._images = np.zeros((64, 4096), dtype=np.uint8)
+        self.weight = 0.0                # model-weighted passes since the last reset
+        self.passes = 0
+        self.record: list | None = None  # (tools/shard_compute_probe.py: the op lists as the rank would run them)
+
+    def _plan(self, ops) -> tuple:
+        """(passes, their model weight, tile bits of the last pass) of the fused plan of `ops` (tile passes possible)"""
+        import ctypes as C
+
+        from quantum_simulations_amd import _lib
+        from quantum_simulations_amd.kernel.device import pack_ops
+        nq, qubits, mats = pack_ops(ops)
+        lib = _lib.load()
+        count = C.c_int32()
+        args = (self.k, len(nq), nq.ctypes.data_as(C.c_void_p), qubits.ctypes.data_as(C.c_void_p), mats.ctypes.data_as(C.c_void_p))
+        images = self._images
+        _lib.check(lib.qsim_plan_ops(*args, images.ctypes.data_as(C.c_void_p), images.nbytes, C.byref(count)))
+        if count.value > len(images):    # (a buffer too small only reports the count)
+            images = self._images = np.zeros((2 * count.value, 4096), dtype=np.uint8)
+            _lib.check(lib.qsim_plan_ops(*args, images.ctypes.data_as(C.c_void_p), images.nbytes, C.byref(count)))
+        weight, last = 0.0, set()
+        for p in range(count.value):     # (pass image = the kernel-argument block: T at byte 12, the tile's high bits from 16)
+            T = int(images[p, 12:16].view("<i4")[0])
+            last = {int(b) for b in images[p, 16:16 + T - 3]}
+            weight += self._tile_layout.tile_cost(self.model, sorted(last)) / self.model_ref if self.model is not None else 1.0
+        return count.value, weight, last
+
+    def apply_ops(self, ops, src=None, dst=None, parts: int = 0, src_parts: int = 0) -> int:
+        self._loads = len(split_pieces(self.k, len(src[1]), src_parts)) if (src is not None and src_parts) else 0
+        for side in (src, dst):
+            if side is not None:
+                self._check(side[1], 0, 1)
+        if dst is not None and parts:
+            self._parts = split_pieces(self.k, len(dst[1]), parts)
+        ops = list(ops)
+        if self.record is not None and ops:
+            self.record.append(ops)
+        if ops and 8 <= self.k <= 35:
+            passes, weight, last = self._plan(ops)
+        else:                            # (shards too small for tile passes: one launch per gate)
+            passes, weight, last = len(ops), float(len(ops)), None
+        tiles = last is not None and passes > 0
+        fused_in = src is not None and tiles and min(src[1]) >= 3
+        fused_out = dst is not None and tiles and min(dst[1]) >= 3 and not (set(dst[1]) & last)
+        extra = int(src is not None and not fused_in) + int(dst is not None and not fused_out)
+        # (qsim_apply_ops_io_own_slab: ONE pass reads the source and stores the slabs)
+        self._own_in_state = bool(src is not None and dst is not None and dst[2] == src[0] and fused_in and fused_out and passes == 1)
+        self.local_passes += 1
+        self.passes += passes + extra
+        self.weight += weight + extra
+        return passes + extra
+
+    def pack_all(self, bits, dst, skip_pattern, piece=0, n_pieces=1) -> None:
+        super().pack_all(bits, dst, skip_pattern, piece, n_pieces)
+        self.weight += 1.0 / n_pieces
+
+    def unpack_all(self, bits, src, skip_pattern, piece=0, n_pieces=1) -> None:
+        super().unpack_all(bits, src, skip_pattern, piece, n_pieces)
+        self.weight += 1.0 / n_pieces
+
+
 class DistributedEngine:
     def __init__(self, n_qubits: int, world: int, rank: int, local_rank: int = 0,
                  mode: str = "fused", backend=None, staging: bool = True,
@@ -361,8 +440,8 @@ class DistributedEngine:
             raise ValueError("layout must be 'auto', 'search' or 'identity'")
         self.layout = layout
         self._fresh = False                        # the state is |0..0> and no plan has chosen a layout for it yet
-        self._model_ref = None                     # (cost model: the average pass over random tiles, set on first use)
-        self._plan_images = np.zeros((64, 4096), dtype=np.uint8)
+        self._shadow = None                        # (the planning twin that prices candidate layouts, made on first use)
+        self.relayout_log: list = []               # slab-bit counts of the re-layouts made since the last reset (shadow engines)
         self.layout_info = None
         self._passes = self.last_passes = 0
         self.home_moves = 0                        # times "state" and "buf1" traded names (one-pass op list between two re-layouts)
@@ -561,82 +640,53 @@ class DistributedEngine:
     # node was available to measure it -- used only to weigh re-layouts against passes when two layouts differ in both.
     RELAYOUT_PASSES = {1: 10.4, 2: 5.2, 3: 2.6}
 
-    def _schedule_cost(self, steps: list) -> tuple:
-        """(cost in pass units, HBM passes of the local op lists, re-layout sizes) of a planned execution: the passes the
-        library's pass builder needs for every step's local ops (qsim_plan_ops: host only, rank independent) and the
-        all-to-all re-layouts its planned cross SWAPs merge into (`run_step`'s grouping: up to three disjoint pairs)."""
-        import ctypes as C
+    def _candidate_cost(self, cd: dict, l2p: list, repeats: int = 1) -> tuple:
+        """(cost in pass units per execution, HBM passes of the first execution, its re-layout sizes) of executing `cd`
+        `repeats` times from |0..0> in the layout `l2p` ON THIS RANK: a shadow engine with a `PlanningBackend` runs the real
+        schedule code -- staging, deferred local batches, rank-bit phases and conditional gates of this rank, fused
+        re-layout ends -- without memory or arithmetic.  Later executions start from the layout the one before left behind;
+        at most three are run, the mean of the second and third standing for all later ones."""
+        sh = self._shadow
+        if sh is None:
+            sh = self._shadow = DistributedEngine(self.n, self.world, self.rank, mode=self.mode, backend=PlanningBackend(self.k),
+                                                  staging=self.staging, staging_method=self.staging_method, init_process_group=False,
+                                                  relayout_pieces=self.relayout_pieces, min_piece_qubits=self.min_piece_qubits,
+                                                  fuse_relayout=self.fuse_relayout, layout="identity")
+        sh.staging = self.staging
+        sh.init_zero_state()
+        sh._fresh = False
+        sh.l2p_planned = list(l2p)
+        run = max(1, min(repeats, 3))
+        plan = sh.plan(cd, repeats=run)
+        costs, first = [], None
+        for _ in range(run):
+            sh.backend.weight, sh.backend.passes, sh.relayout_log = 0.0, 0, []
+            sh.execute(plan)
+            costs.append(sh.backend.weight + sum(self.RELAYOUT_PASSES[m] for m in sh.relayout_log))
+            first = first or (sh.last_passes, list(sh.relayout_log))
+        later = float(np.mean(costs[1:])) if run > 1 else 0.0
+        return (costs[0] + (max(1, repeats) - 1) * later) / max(1, repeats), first[0], first[1]
 
-        from quantum_simulations_amd import _lib
-        from quantum_simulations_amd.kernel.device import pack_ops
-        from quantum_simulations_amd.runner import tile_layout
-        lib = _lib.load()
-        # Shards of 26 local qubits and more: a pass is priced by the DRAM pattern of its tile's index bits (the one-GPU
-        # engine's model, runner/tile_layout.py, in units of the model's average pass over random tiles), not counted as
-        # 1: two layouts with the same number of passes differ by a few percent in what the passes cost.
-        model = tile_layout.model_for(self.k) if self.k >= 26 else None
-        if model is not None and self._model_ref is None:
-            rng = np.random.default_rng(7)
-            top = min(self.k - 1, model["top"])
-            self._model_ref = float(np.mean([tile_layout.tile_cost(model, rng.choice(np.arange(3, top + 1), size=8, replace=False))
-                                             for _ in range(256)]))
-        passes, weight, extra, groups = 0, 0.0, 0, []
-        for step in steps:
-            ops = list(step["local_ops"])
-            if ops and 8 <= self.k <= 35:
-                nq, qubits, mats = pack_ops(ops)
-                count = C.c_int32()
-                args = (self.k, len(nq), nq.ctypes.data_as(C.c_void_p), qubits.ctypes.data_as(C.c_void_p), mats.ctypes.data_as(C.c_void_p))
-                if model is None:
-                    _lib.check(lib.qsim_plan_ops(*args, None, 0, C.byref(count)))
-                    weight += count.value
-                else:
-                    images = self._plan_images
-                    _lib.check(lib.qsim_plan_ops(*args, images.ctypes.data_as(C.c_void_p), images.nbytes, C.byref(count)))
-                    if count.value > len(images):    # (a buffer too small only reports the count)
-                        images = self._plan_images = np.zeros((2 * count.value, 4096), dtype=np.uint8)
-                        _lib.check(lib.qsim_plan_ops(*args, images.ctypes.data_as(C.c_void_p), images.nbytes, C.byref(count)))
-                    for p in range(count.value):     # (pass image = the kernel-argument block: T at byte 12, the tile's high bits from 16)
-                        T = int(images[p, 12:16].view("<i4")[0])
-                        weight += tile_layout.tile_cost(model, [int(b) for b in images[p, 16:16 + T - 3]]) / self._model_ref
-                passes += count.value
-            else:
-                passes += len(ops)                   # (shards too small for tile passes: one launch per gate)
-                weight += len(ops)
-            group, used = 0, set()
-            for op in list(step["nonlocal_ops"]) + [None]:
-                cross = op is not None and self._is_planned_swap(op) and self._is_cross(list(op[0]))
-                if group and not (cross and group < 3 and used.isdisjoint(op[0])):
-                    # the group is complete: one re-layout.  With local bits inside a 128-byte line it cannot ride in the
-                    # neighbouring tile passes: a pack and an unpack pass of the shard (`relayout`, unfused branch)
-                    groups.append(group)
-                    if self.fuse_relayout and min(used) < 3:
-                        extra += 2
-                    group, used = 0, set()
-                if cross:
-                    group += 1
-                    used.update(op[0])
-        return weight + extra + sum(self.RELAYOUT_PASSES[m] for m in groups), passes + extra, groups
-
-    def choose_initial_layout(self, cd: dict, n_candidates: int | None = None, seed: int = 20260504) -> list:
+    def choose_initial_layout(self, cd: dict, n_candidates: int | None = None, seed: int = 20260504, repeats: int = 1) -> list:
         """l2p for a state that is still |0..0>: the identity or one of `n_candidates` random assignments, whichever gives
-        the staged schedule of `cd` the lowest `_schedule_cost` (ties: the earlier candidate, the identity first).  Every
-        rank computes the same list (same inputs, same code); rank 0's is broadcast and used."""
+        the staged schedule of `cd` the lowest cost on the SLOWEST rank (`_candidate_cost` per rank, maximum over the ranks:
+        they run different op lists; ties: the earlier candidate, the identity first).  COLLECTIVE."""
         n_candidates = self.LAYOUT_CANDIDATES if n_candidates is None else n_candidates
         rng = np.random.default_rng(seed)
         cands = [list(range(self.n))] + [[int(x) for x in rng.permutation(self.n)] for _ in range(n_candidates)]
-        scored = []
-        for l2p in cands:
-            steps, _ = self._steps_from(cd, l2p)
-            scored.append(self._schedule_cost(steps))
-        best = min(range(len(cands)), key=lambda i: (scored[i][0], i))
-        box = [cands[best], {"candidates": len(cands),
-                             "identity": {"cost": round(scored[0][0], 2), "passes": scored[0][1], "relayouts": scored[0][2]},
-                             "chosen": {"cost": round(scored[best][0], 2), "passes": scored[best][1], "relayouts": scored[best][2], "index": best}}]
+        scored = [self._candidate_cost(cd, l2p, repeats) for l2p in cands]
+        costs = self.torch.tensor([c for c, _, _ in scored], dtype=self.torch.float64)
         if self.dist.is_initialized() and self.world > 1:
-            self.dist.broadcast_object_list(box, src=0)
-        self.layout_info = box[1]
-        return box[0]
+            if self.dist.get_backend() == "nccl":
+                costs = costs.cuda()
+            self.dist.all_reduce(costs, op=self.dist.ReduceOp.MAX)
+            costs = costs.cpu()
+        best = min(range(len(cands)), key=lambda i: (float(costs[i]), i))
+        self.layout_info = {"candidates": len(cands), "executions_planned_for": max(1, repeats),
+                            "identity": {"cost_max_over_ranks": round(float(costs[0]), 2), "passes_this_rank": scored[0][1], "relayouts": scored[0][2]},
+                            "chosen": {"cost_max_over_ranks": round(float(costs[best]), 2), "passes_this_rank": scored[best][1],
+                                       "relayouts": scored[best][2], "index": best}}
+        return cands[best]
 
     def plan(self, circuit_dict: dict, repeats: int = 1) -> Plan:
         """Step lists for `repeats` successive executions from the engine's current layout.  COLLECTIVE when it is the first
@@ -649,7 +699,7 @@ class DistributedEngine:
             # (once per initialised state: a second plan made before the first one runs keeps this layout, so both stay valid)
             self._fresh = False
             if self.staging and self.world > 1 and self.k >= 2 and (self.layout == "search" or (self.layout == "auto" and self.k >= 20)):
-                self.l2p_planned = self.choose_initial_layout(cd)
+                self.l2p_planned = self.choose_initial_layout(cd, repeats=max(1, repeats))
         executions, mappings, starts = [], [], []
         l2p = list(self.l2p_planned)
         for _ in range(max(1, repeats)):
@@ -755,6 +805,7 @@ class DistributedEngine:
         loc = [min(p) for p in pairs]
         glo = [max(p) for p in pairs]
         m = len(pairs)
+        self.relayout_log.append(m)
         slab = 2 << (self.k - m)                       # float64 elements per slab
         mine = sum(((self.rank >> (g - self.k)) & 1) << i for i, g in enumerate(glo))
         send = self.backend.tensor("buf0")
@@ -1108,7 +1159,7 @@ class DistributedEngine:
                 "exchange_ms_rank0": ms, "exchange_ms_max_over_ranks": ms_max}
 
     def reset_comm_stats(self) -> None:
-        self.xgmi_bytes_sent, self.exchanges, self._comm_events = 0, 0, []
+        self.xgmi_bytes_sent, self.exchanges, self._comm_events, self.relayout_log = 0, 0, [], []
 
     def close(self) -> None:
         self.backend.close()

@@ -13,21 +13,41 @@ def _engine(n, world, **kw):
     return DistributedEngine(n, world, 0, backend=DryBackend(n - p), init_process_group=False, **kw)
 
 
-def test_cost_counts_passes_relayouts_and_unfusable_ones():
-    eng = _engine(24, 4, layout="identity")
-    k = eng.k
+def test_planning_backend_counts_what_the_library_would_do():
+    """PlanningBackend.apply_ops = the HBM passes of qsim_apply_ops_io: planned tile passes, + 1 for every end that cannot
+    ride in one (slab bits inside a line, a slab bit among the last pass's tile bits, nothing to plan)."""
+    from quantum_simulations_amd.runner.distributed import PlanningBackend
+    k = 20
+    be = PlanningBackend(k)
     H = np.array([[1, 1], [1, -1]]) / np.sqrt(2)
-    SWAP = np.eye(4)[[0, 2, 1, 3]]
-    local = [([q], H) for q in range(3, 9)]                     # one fused pass
-    steps = [{"local_ops": local, "nonlocal_ops": [([5, k], SWAP), ([6, k + 1], SWAP)]},          # one re-layout, m = 2
-             {"local_ops": local, "nonlocal_ops": [([1, k], SWAP)]},                               # m = 1, a line bit: + 2 passes
-             {"local_ops": [], "nonlocal_ops": [([7, k], SWAP), ([7, k + 1], SWAP)]}]             # not disjoint: two of m = 1
-    cost, passes, groups = eng._schedule_cost(steps)
-    assert groups == [2, 1, 1, 1]
-    assert passes == 1 + 1 + 2
-    assert cost == pytest.approx(passes + eng.RELAYOUT_PASSES[2] + 3 * eng.RELAYOUT_PASSES[1])
-    eng.fuse_relayout = False                                    # (unfused engines pay pack + unpack everywhere: no extra term)
-    assert eng._schedule_cost(steps)[1] == 2
+    ops = [([q], H) for q in range(3, 9)]                                  # one fused pass on qubits 3..8
+    assert be.apply_ops(ops) == 1
+    assert be.apply_ops(ops, src=("buf1", [18, 19])) == 1                  # first pass reads the slabs
+    assert be.apply_ops(ops, dst=("buf0", [18, 19], "buf1", 2)) == 1       # last pass stores them
+    assert be.apply_ops(ops, src=("buf1", [1, 19])) == 2                   # a slab bit inside a 128-byte line: unpack pass
+    assert be.apply_ops(ops, dst=("buf0", [5, 19], "buf1", 0)) == 2        # a slab bit is a tile bit of the last pass: pack pass
+    assert be.apply_ops([], src=("buf1", [18]), dst=("buf0", [17], "buf1", 1)) == 2     # nothing to plan: unpack + pack
+    assert not be.own_slab_in_state()
+    assert be.apply_ops(ops, src=("buf1", [18]), dst=("buf0", [17], "buf1", 1)) == 1 and be.own_slab_in_state()
+    many = [([q], H) for q in range(3, 20)] * 2                            # more targets than a tile holds: several passes
+    assert be.apply_ops(many, src=("buf1", [18]), dst=("buf0", [17], "buf1", 1)) >= 2 and not be.own_slab_in_state()
+    small = PlanningBackend(6)                                             # shards too small for tile passes: a launch per gate
+    assert small.apply_ops([([1], H), ([2], H)]) == 2 and small.weight == 2.0
+
+
+def test_shadow_engine_prices_a_candidate_like_the_real_run():
+    """`_candidate_cost` executes the schedule on a PlanningBackend: its pass count equals what a dry engine of the same
+    configuration reports for the same circuit and layout (same code path), and the re-layouts are logged by size."""
+    n, world = 24, 4
+    cd = validate_circuit_dict(gen.random_clifford_t_circuit(n, depth=30))
+    eng = _engine(n, world, layout="identity")
+    cost, passes, relayouts = eng._candidate_cost(cd, list(range(n)))
+    assert passes > 0 and relayouts and all(m in (1, 2) for m in relayouts)
+    assert cost == pytest.approx(passes + sum(eng.RELAYOUT_PASSES[m] for m in relayouts))     # (k < 26: every pass weighs 1)
+    again = eng._candidate_cost(cd, list(range(n)))
+    assert again == (cost, passes, relayouts)                                # the shadow engine starts afresh every time
+    eng.staging = False                                                      # swap-and-stay moves are re-layouts too
+    assert eng._candidate_cost(cd, list(range(n)))[2]
 
 
 @pytest.mark.parametrize("n,world,circuit", [(26, 4, "clifft"), (27, 8, "rand"), (26, 4, "ghz_qft")])
@@ -39,11 +59,10 @@ def test_choice_is_never_dearer_than_the_identity_and_is_reproducible(n, world, 
     first = eng.choose_initial_layout(cd, n_candidates=12)
     info = eng.layout_info
     assert sorted(first) == list(range(n))
-    assert info["chosen"]["cost"] <= info["identity"]["cost"] and info["candidates"] == 13
+    assert info["chosen"]["cost_max_over_ranks"] <= info["identity"]["cost_max_over_ranks"] and info["candidates"] == 13
     assert (info["chosen"]["index"] == 0) == (first == list(range(n)))
     assert eng.choose_initial_layout(cd, n_candidates=12) == first          # same inputs, same answer (every rank computes it)
-    steps, _ = eng._steps_from(cd, first)
-    assert eng._schedule_cost(steps)[0] == pytest.approx(info["chosen"]["cost"], abs=0.006)
+    assert eng._candidate_cost(cd, first)[0] == pytest.approx(info["chosen"]["cost_max_over_ranks"], abs=0.006)
 
 
 def test_only_the_first_plan_of_a_fresh_state_chooses():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One GPU: what the partition's initial layout is worth in per-GPU COMPUTE time.  Rank 0's staged schedule of a circuit on
-N ranks is planned under the identity and under the layout `DistributedEngine.choose_initial_layout` picks; the local op
-lists of every step run on ONE shard-sized chunk (same kernels, same plans as on the node; the exchanges are skipped -- the
+N ranks is planned under the identity and under the layout `DistributedEngine.choose_initial_layout` picks; the op lists
+rank 0 would hand to the library (recorded by the engine's planning twin) run on ONE shard-sized chunk (same kernels, same plans as on the node; the exchanges are skipped -- the
 data is meaningless, the timing is not; the slab stores of the fused re-layouts are not part of it) and are timed.
     python tools/shard_compute_probe.py [N_QUBITS N_RANKS]"""
 import sys
@@ -28,8 +28,11 @@ for name, cd in (("random 1q+CX depth 40", gen.random_1q_cx_circuit(n, depth=40)
     info = eng.layout_info
     row = []
     for label, l2p in (("identity", list(range(n))), ("chosen", chosen)):
-        steps, _ = eng._steps_from(cd, l2p)
-        lists = [pack_ops(s["local_ops"]) for s in steps if len(s["local_ops"])]
+        eng._candidate_cost(cd, l2p)                        # (makes the shadow engine)
+        eng._shadow.backend.record = []
+        eng._candidate_cost(cd, l2p)                        # the op lists exactly as rank 0 would hand them to the library:
+        lists = [pack_ops(ops) for ops in eng._shadow.backend.record]      # deferred batches merged, rank-bit phases and
+        eng._shadow.backend.record = None                   # conditional gates of rank 0 included
         for ops in lists:                                   # warm-up: plans into the cache
             chunk.apply_ops(ops)
         chunk.sync()
@@ -42,6 +45,6 @@ for name, cd in (("random 1q+CX depth 40", gen.random_1q_cx_circuit(n, depth=40)
         row.append((label, passes, best * 1e3))
     (_, p0, t0_), (_, p1, t1_) = row
     print(f"n={n} on {world} ranks ({k} local qubits), {name}: identity {p0} passes {t0_:.1f} ms  ->  chosen {p1} passes {t1_:.1f} ms "
-          f"({(t0_ / t1_ - 1) * 100:+.1f} % compute rate); model {info['identity']['cost']} -> {info['chosen']['cost']} pass units, "
+          f"({(t0_ / t1_ - 1) * 100:+.1f} % compute rate); model {info['identity']['cost_max_over_ranks']} -> {info['chosen']['cost_max_over_ranks']} pass units, "
           f"re-layouts {info['identity']['relayouts']} -> {info['chosen']['relayouts']}", flush=True)
 chunk.close()
