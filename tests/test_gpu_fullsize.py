@@ -216,6 +216,7 @@ def _worker(rank, world, port, errors, results):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         sys.path.insert(0, str(ROOT))
+        from quantum_simulations_amd.circuit.io import validate_circuit_dict
         from quantum_simulations_amd.runner.distributed import DistributedEngine, HipShardBackend
         cd = _config4_circuit()
         want = _oracle_state(cd) if rank == 0 else None
@@ -225,7 +226,15 @@ def _worker(rank, world, port, errors, results):
             assert eng.relayout_pieces == 4 and eng.min_piece_qubits == 20          # the defaults
             assert eng._relayout_pieces(N4 - p - 2) == 4                             # slabs really split
             eng.init_zero_state()
-            eng.execute(eng.plan(cd))
+            plan = eng.plan(cd)
+            eng.execute(plan)
+            if staging:
+                # the layout search priced this run on a planning twin: what the twin counted for the
+                # chosen layout is what this rank's library really did -- tile passes, fused and unfused re-layout ends
+                assert eng.layout_info is not None and (eng.layout_info["chosen"]["passes_this_rank"] == eng.last_passes or not fuse), \
+                    (rank, eng.layout_info, eng.last_passes)
+                twin = eng._candidate_cost(validate_circuit_dict(cd), plan.start_mappings[0])
+                assert twin[1] == eng.last_passes, (rank, fuse, twin, eng.last_passes)
             stats = eng.comm_stats()
             norm2 = eng.norm2()
             got = eng.state_vector()                                                # gathered, logical order
