@@ -434,7 +434,7 @@ class DistributedEngine:
         # Initial qubit layout (round 4): |0..0> is the same state under every assignment of qubits to index bits, so the first
         # plan after `init_zero_state` may start from any -- which qubits are global first, which three sit on the line bits
         # (they belong to every tile) -- and the staged schedule that follows differs in re-layouts and HBM passes:
-        # `plan` tries LAYOUT_CANDIDATES random assignments beside the identity and keeps the cheapest (`_schedule_cost`).
+        # `plan` tries LAYOUT_CANDIDATES random assignments beside the identity and keeps the cheapest (`_candidate_cost`: each one executed on a planning twin of this engine).
         # "auto": staged runs with shards of >= 20 local qubits; "search": always (tests); "identity": never.
         if layout not in ("auto", "search", "identity"):
             raise ValueError("layout must be 'auto', 'search' or 'identity'")
