@@ -1,7 +1,7 @@
 """Dry run of the multi-GPU communication schedule (bench.py --gpus N --dry-run, CPU tests).
 
 Every rank runs the REAL `DistributedEngine` -- planning, staging, swap-and-stay moves, pipelined
-re-layout pieces -- at the full problem size (30 local qubits, n = 32 / 33) over a `DryBackend` that
+re-layout pieces -- at the full problem size (30 local qubits, n = 32 / 33) over a `PlanningBackend` that
 holds no shard memory and does no arithmetic; each transfer the engine would post is recorded instead
 (peer, bytes sent, bytes expected, kind).  The ranks then exchange their records over gloo and rank 0
 checks what a first run on real RCCL / xGMI would otherwise have to discover:
@@ -18,7 +18,7 @@ from __future__ import annotations
 import json
 
 from quantum_simulations_amd import circuits as gen
-from quantum_simulations_amd.runner.distributed import DistributedEngine, DryBackend
+from quantum_simulations_amd.runner.distributed import DistributedEngine, PlanningBackend
 
 
 def workloads(n: int) -> list:
@@ -59,17 +59,22 @@ def run_world(world: int, rank: int, k: int, emit=print) -> int:
     failed = 0
     eng = None
     for title, cd, staging, repeats in workloads(n):
-        eng = DistributedEngine(n, world, rank, backend=DryBackend(k), staging=staging)
+        # (a PlanningBackend: the dry run also knows the HBM passes every rank's library would make -- qsim_plan_ops on the
+        # exact op lists, host only -- so the line carries the compute side of the schedule next to its transfers)
+        eng = DistributedEngine(n, world, rank, backend=PlanningBackend(k), staging=staging)
         eng.init_zero_state()
         plan = eng.plan(cd, repeats=repeats)
+        passes = []
         for _ in range(repeats):
             eng.execute(plan)
+            passes.append(eng.last_passes)
         traces = [None] * world
         dist.all_gather_object(traces, eng.trace)
         stats = [None] * world
         dist.all_gather_object(stats, {"bytes": eng.xgmi_bytes_sent, "exchanges": eng.exchanges,
                                        "local_batches": eng.backend.local_passes, "layout": eng.l2p,
-                                       "groups_posted": eng.trace_posts})
+                                       "groups_posted": eng.trace_posts, "hbm_passes": passes,
+                                       "layout_search": eng.layout_info})
         if rank == 0:
             problems = check(traces, world, k)
             failed += bool(problems)
@@ -83,11 +88,14 @@ def run_world(world: int, rank: int, k: int, emit=print) -> int:
                 "executions": repeats, "ok": not problems, "problems": problems[:8],
                 "per_rank": [{"rank": r, "transfers": len(traces[r]), "bytes_sent": stats[r]["bytes"],
                               "exchanges": stats[r]["exchanges"], "local_batches": stats[r]["local_batches"],
+                              # HBM passes of the shard per execution, as the library's host planner plans this rank's op lists
+                              "hbm_passes_per_execution": stats[r]["hbm_passes"],
                               # posting points: a fused re-layout posts one group (all peers at once) per piece
                               "groups_posted": stats[r]["groups_posted"]}
                              for r in range(world)],
                 "rank0_by_kind": {kd: {"transfers": c, "bytes": b} for kd, (c, b) in kinds.items()},
                 "rank0_schedule": [{"kind": kind, "peer": peer, "bytes": s} for kind, peer, s, _ in traces[0][:64]],
+                "layout_search_rank0": stats[0]["layout_search"],
                 "final_layout_rank0": stats[0]["layout"]}))
     flag = [failed]
     dist.broadcast_object_list(flag, src=0)
