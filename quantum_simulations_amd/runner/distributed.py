@@ -435,7 +435,7 @@ class DistributedEngine:
         # plan after `init_zero_state` may start from any -- which qubits are global first, which three sit on the line bits
         # (they belong to every tile) -- and the staged schedule that follows differs in re-layouts and HBM passes:
         # `plan` tries LAYOUT_CANDIDATES random assignments beside the identity and keeps the cheapest (`_candidate_cost`: each one executed on a planning twin of this engine).
-        # "auto": staged runs with shards of >= 20 local qubits; "search": always (tests); "identity": never.
+        # "auto": shards of >= 20 local qubits (staged or swap-and-stay schedules alike); "search": always (tests); "identity": never.
         if layout not in ("auto", "search", "identity"):
             raise ValueError("layout must be 'auto', 'search' or 'identity'")
         self.layout = layout
@@ -698,7 +698,7 @@ class DistributedEngine:
         if self._fresh:
             # (once per initialised state: a second plan made before the first one runs keeps this layout, so both stay valid)
             self._fresh = False
-            if self.staging and self.world > 1 and self.k >= 2 and (self.layout == "search" or (self.layout == "auto" and self.k >= 20)):
+            if self.world > 1 and self.k >= 2 and (self.layout == "search" or (self.layout == "auto" and self.k >= 20)):
                 self.l2p_planned = self.choose_initial_layout(cd, repeats=max(1, repeats))
         executions, mappings, starts = [], [], []
         l2p = list(self.l2p_planned)
@@ -1133,7 +1133,7 @@ class DistributedEngine:
                               # only) over the run's wall time -- pieces overlap compute, so this is an upper bound of
                               # what the links cost
                               "exchange_time_share": (round(ms * 1e-3 / dt, 4) if ms is not None else None),
-                              "layout": self.layout_info if staging else None}
+                              "layout": self.layout_info}
                 runs.append((self.fingerprints(seed), self.shard_selectors()))
             self.staging = saved
             if check_amplitudes:

@@ -221,20 +221,26 @@ def _worker(rank, world, port, errors, results):
         cd = _config4_circuit()
         want = _oracle_state(cd) if rank == 0 else None
         p = world.bit_length() - 1
-        for staging, fuse in ((True, True), (False, True), (True, False), (False, False)):
-            eng = DistributedEngine(N4, world, rank, backend=HipShardBackend(N4 - p, 0), staging=staging, fuse_relayout=fuse)
+        # the default pipeline (layout search on: "auto" at 24 local qubits) staged and unstaged, then the four combinations
+        # of staging x fused re-layouts in ONE layout (the identity), whose pass counts are compared below
+        for staging, fuse, layout in ((True, True, "auto"), (False, True, "auto"), (True, True, "identity"), (False, True, "identity"),
+                                      (True, False, "identity"), (False, False, "identity")):
+            eng = DistributedEngine(N4, world, rank, backend=HipShardBackend(N4 - p, 0), staging=staging, fuse_relayout=fuse, layout=layout)
             assert eng.relayout_pieces == 4 and eng.min_piece_qubits == 20          # the defaults
             assert eng._relayout_pieces(N4 - p - 2) == 4                             # slabs really split
             eng.init_zero_state()
             plan = eng.plan(cd)
             eng.execute(plan)
-            if staging:
-                # the layout search priced this run on a planning twin: what the twin counted for the
-                # chosen layout is what this rank's library really did -- tile passes, fused and unfused re-layout ends
-                assert eng.layout_info is not None and (eng.layout_info["chosen"]["passes_this_rank"] == eng.last_passes or not fuse), \
-                    (rank, eng.layout_info, eng.last_passes)
-                twin = eng._candidate_cost(validate_circuit_dict(cd), plan.start_mappings[0])
-                assert twin[1] == eng.last_passes, (rank, fuse, twin, eng.last_passes)
+            # the layout search prices candidates on a planning twin: what the twin counts for a layout is
+            # what this rank's library really does -- tile passes, fused and unfused re-layout ends, swap-and-stay moves
+            twin = eng._candidate_cost(validate_circuit_dict(cd), plan.start_mappings[0])
+            assert twin[1] == eng.last_passes, (rank, staging, fuse, layout, twin, eng.last_passes)
+            if layout == "auto":
+                info = eng.layout_info
+                assert info is not None and info["chosen"]["passes_this_rank"] == eng.last_passes, (rank, info, eng.last_passes)
+                assert info["chosen"]["cost_max_over_ranks"] <= info["identity"]["cost_max_over_ranks"]
+            else:
+                assert eng.layout_info is None and plan.start_mappings[0] == list(range(N4))
             stats = eng.comm_stats()
             norm2 = eng.norm2()
             got = eng.state_vector()                                                # gathered, logical order
@@ -244,8 +250,8 @@ def _worker(rank, world, port, errors, results):
                     bad = np.flatnonzero(np.abs(got - want) > 1e-10)
                     print(f"[staging={staging}] {bad.size} wrong amplitudes, first {bad[:8].tolist()}, last {int(bad[-1])}, "
                           f"AND {int(np.bitwise_and.reduce(bad)):#x} OR {int(np.bitwise_or.reduce(bad)):#x}", file=sys.stderr, flush=True)
-                results.put((staging, fuse, err, norm2, stats["exchanges"], stats["bytes_sent_per_rank"], eng.last_passes))
-            if fuse:
+                results.put((staging, fuse, layout, err, norm2, stats["exchanges"], stats["bytes_sent_per_rank"], eng.last_passes))
+            if fuse and layout == "auto":
                 # the amplitude check that needs no gather: per-shard fingerprints in the staged /
                 # moved layout against the same index sets of a ONE-device run of the circuit (the product hook: a
                 # 26-qubit SingleGpuEngine on rank 0's device), then the same after two slabs traded places
@@ -293,11 +299,12 @@ def test_config4_clifford_t_26q_four_ranks_default_pipeline():
     assert not msgs and all(p.exitcode == 0 for p in procs), "\n".join(f"[rank {r}] {m}" for r, m in msgs)
     seen, passes = {}, {}
     while not results.empty():
-        staging, fuse, err, norm2, exchanges, sent, n_passes = results.get()
-        passes[(staging, fuse)] = (n_passes, exchanges)
-        if fuse:
+        staging, fuse, layout, err, norm2, exchanges, sent, n_passes = results.get()
+        if layout == "identity":
+            passes[(staging, fuse)] = (n_passes, exchanges)
+        else:
             seen[staging] = (err, exchanges, sent)
-        assert err < 1e-10, f"staging={staging} fuse={fuse}: max |amp - C oracle| = {err}"
+        assert err < 1e-10, f"staging={staging} fuse={fuse} layout={layout}: max |amp - C oracle| = {err}"
         assert abs(norm2 - 1.0) < 1e-10
     assert set(seen) == {True, False} and len(passes) == 4
     assert 0 < seen[True][1] <= seen[False][1]                  # staging needs no more exchanges than swap-and-stay

@@ -88,12 +88,19 @@ def test_only_the_first_plan_of_a_fresh_state_chooses():
     assert eng.plan(cd).start_mappings[0] == list(range(n))
 
 
-def test_auto_needs_staging_and_real_shard_sizes():
+def test_auto_needs_real_shard_sizes_and_unstaged_schedules_are_searched_too():
     cd = gen.random_clifford_t_circuit(12, depth=10)
-    for kw in ({"layout": "auto"}, {"layout": "identity"}, {"layout": "search", "staging": False}):
+    for kw in ({"layout": "auto"}, {"layout": "identity"}):
         eng = _engine(12, 4, **kw)
         eng.init_zero_state()
         eng.plan(cd)
         assert eng.l2p_planned == list(range(12)) and eng.layout_info is None, kw
+    eng = _engine(12, 4, layout="search", staging=False)       # swap-and-stay moves are priced like planned re-layouts
+    eng.LAYOUT_CANDIDATES = 6
+    eng.init_zero_state()
+    eng.plan(cd)
+    info = eng.layout_info
+    assert info is not None and info["chosen"]["cost_max_over_ranks"] <= info["identity"]["cost_max_over_ranks"]
+    assert all(m in (1, 2) for m in info["identity"]["relayouts"])
     with pytest.raises(ValueError):
         _engine(12, 4, layout="best")

@@ -91,7 +91,7 @@ def main():
             phase[0] = f"config 4 {label}: executing"
             eng.staging = staging
             dt, steps = timed_run(eng, cd)
-            rec[label] = {"seconds": round(dt, 4), "gate_apps_per_s": round(len(cd["gates"]) / dt, 1), "steps": steps, "layout": eng.layout_info if staging else None,
+            rec[label] = {"seconds": round(dt, 4), "gate_apps_per_s": round(len(cd["gates"]) / dt, 1), "steps": steps, "layout": eng.layout_info,
                           "hbm_passes": eng.last_passes, "home_moves_max_over_ranks": int(eng.max_over_ranks(float(eng.home_moves))), "norm2": eng.norm2(), "xgmi": eng.comm_stats()}
             runs.append((eng.fingerprints(seed), eng.shard_selectors()))
             labels.append(label)
