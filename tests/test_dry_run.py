@@ -58,6 +58,16 @@ def test_schedule_is_symmetric_at_full_size(world):
             assert r["groups_posted"] >= 2 * r["exchanges"] > 0 or r["exchanges"] == 0, r
         sent = {r["bytes_sent"] for r in d["per_rank"]}
         assert len(sent) == 1, "every rank ships the same number of bytes"        # (the schedule is symmetric)
+        # the compute side: every rank's HBM passes per execution as the library's host planner plans ITS op lists (the ranks
+        # differ by their rank-bit phases and conditional gates: a pass or two), and the layout search that preceded it
+        for r in d["per_rank"]:
+            assert len(r["hbm_passes_per_execution"]) == d["executions"] and all(x > 0 for x in r["hbm_passes_per_execution"])
+        spread = [max(r["hbm_passes_per_execution"][e] for r in d["per_rank"]) - min(r["hbm_passes_per_execution"][e] for r in d["per_rank"])
+                  for e in range(d["executions"])]
+        assert max(spread) <= 4, spread
+        info = d["layout_search_rank0"]
+        assert info is not None and info["chosen"]["cost_max_over_ranks"] <= info["identity"]["cost_max_over_ranks"]
+        assert info["chosen"]["passes_this_rank"] == d["per_rank"][0]["hbm_passes_per_execution"][0]     # what was priced is what ran
     # GHZ needs exactly one re-layout of all global qubits: (1 - 2^-p) of a shard per rank
     ghz = next(d for d in docs if d["dry_run"] == "config 5: GHZ")
     p = world.bit_length() - 1
