@@ -119,6 +119,9 @@ int qsim_apply_ops_tiled(qsim_chunk* c, int n_ops, const int32_t* nq, const int3
  * Parts that cannot be fused (a slab bit inside a 128-byte line, fewer qubits than a tile holds, no ops, a slab bit
  * among the tile bits of the last pass) run as separate slab passes; *n_passes reports the HBM passes made. */
 typedef struct {
+  uint32_t struct_size;  /* = sizeof(qsim_ops_io) of the header the caller was built against: a host built against another
+                          * layout of this struct is refused (QSIM_ERR_INVALID) instead of being read past its end.  Zero the
+                          * struct (memset), set struct_size, then the fields you use. */
   const qsim_chunk* src; int32_t src_m; int32_t src_bits[3];
   qsim_chunk* dst; int32_t dst_m; int32_t dst_bits[3];
   qsim_chunk* dst_own; int32_t own_pattern;
@@ -139,6 +142,10 @@ typedef struct {
                         * with the last piece), everything else of the list with the last piece -- the receive side of a
                         * fused re-layout overlaps its first pass with the links.  With dst_parts too, the slab pieces of
                         * the destination are stored (qsim_apply_ops_io_part) after the last load. */
+  int32_t n_tiles;     /* > 0: the high tile bits of the first n_tiles fused passes are named by the caller (tile_masks[p], bit b:
+                        * index bit b is a tile bit of pass p), as in qsim_apply_ops_tiled: a host that planned stage boundaries
+                        * and passes together (qsim_plan_peek_pass) gets the passes it planned on every rank. */
+  const uint64_t* tile_masks;
 } qsim_ops_io;
 int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits,
                       const double* mats, const qsim_ops_io* io, int* n_passes);
@@ -159,6 +166,17 @@ int qsim_plan_ops(int n_local_qubits, int n_ops, const int32_t* nq, const int32_
                   void* out, uint64_t out_capacity_bytes, int32_t* n_passes);
 int qsim_plan_ops_tiled(int n_local_qubits, int n_ops, const int32_t* nq, const int32_t* qubits, const double* mats,
                         int n_tiles, const uint64_t* tile_masks, void* out, uint64_t out_capacity_bytes, int32_t* n_passes);
+
+/* The next fused pass of a partly executed op list on a PARTITIONED state, without a device (the pass builder as the
+ * partition planner sees it: runner/partition_plan.py, which replaces the per-stage view of wenbo_engine/circuit/
+ * staging.py:447-519 `_local_sets_to_steps`).  Qubits are index bits of the whole state; bits >= n_local_qubits are rank
+ * bits: fine as controls / phase bits, never tile bits or targets (an op that targets one waits and blocks its
+ * dependents).  done[i] != 0: op i ran already.  Out: the tile the builder would choose now (tile_mask: 8 high bits incl.
+ * the fill, which leaves out avoid_mask where it can; need_mask: those its ops need) and the ops it would hold (members,
+ * capacity n_ops); *n_members = 0 when everything left waits for a rank bit.  hint_mask != 0 names the tile. */
+int qsim_plan_peek_pass(int n_local_qubits, int n_total_qubits, int n_ops, const int32_t* nq, const int32_t* qubits,
+                        const double* mats, const uint8_t* done, uint64_t avoid_mask, uint64_t hint_mask, uint64_t* tile_mask,
+                        uint64_t* need_mask, int32_t* n_members, int32_t* members);
 
 /* Pass counts of ONE op list under n_layouts qubit layouts (layouts[l * n_local_qubits + q] = index bit of logical qubit q),
  * planned in parallel on n_threads host threads, no device: the pass builder's result depends on which qubits live on the

@@ -62,6 +62,8 @@ SIGNATURES = {
     "qsim_apply_ops_tiled": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P]),
     "qsim_choose_layout": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, C.c_uint64, C.c_int, _P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "qsim_plan_count_layouts": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int]),
+    "qsim_plan_peek_pass": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_uint64), C.POINTER(C.c_int32), _P]),
     "qsim_last_pass_count": (C.c_int, [_P]),
     "qsim_apply_ops_io": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.POINTER(C.c_int)]),
     "qsim_apply_ops_io_part": (C.c_int, [_P, C.c_int]),
@@ -116,9 +118,15 @@ SIGNATURES = {
 
 class OpsIo(C.Structure):
     """qsim_ops_io (include/qsim_hip.h): buffers a re-layout is fused with at the ends of an op list."""
-    _fields_ = [("src", C.c_void_p), ("src_m", C.c_int32), ("src_bits", C.c_int32 * 3),
+    _fields_ = [("struct_size", C.c_uint32),
+                ("src", C.c_void_p), ("src_m", C.c_int32), ("src_bits", C.c_int32 * 3),
                 ("dst", C.c_void_p), ("dst_m", C.c_int32), ("dst_bits", C.c_int32 * 3),
-                ("dst_own", C.c_void_p), ("own_pattern", C.c_int32), ("dst_parts", C.c_int32), ("src_parts", C.c_int32)]
+                ("dst_own", C.c_void_p), ("own_pattern", C.c_int32), ("dst_parts", C.c_int32), ("src_parts", C.c_int32),
+                ("n_tiles", C.c_int32), ("tile_masks", C.c_void_p)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(OpsIo)       # (the library refuses a struct of another size)
 
 
 class OpList(C.Structure):

@@ -496,6 +496,52 @@ int qsim_plan_ops_tiled(int n_local_qubits, int n_ops, const int32_t* nq, const 
   return rc;
 }
 
+// The NEXT fused pass of a partly executed op list on a partitioned state (the partition planner's view of the pass builder,
+// runner/partition_plan.py): qubits are index bits of the WHOLE state, the bits >= n_local_qubits are rank bits -- an op may
+// use them as controls or phase bits (the rank applies or skips it by its own bits) but an op that TARGETS one has to wait
+// for a re-layout and blocks what depends on it.  done[i] != 0: op i ran already.  Out: the high tile bits the pass builder
+// would choose now (tile_mask, filled to a whole tile; need_mask: the ones its ops need), and the ops it would hold
+// (members, ascending; capacity n_ops).  avoid_mask: bits the fill should leave out (slab bits of the re-layout that follows).
+// hint_mask != 0: that tile instead of a searched one.  An empty pass (everything waits for a rank bit) is reported as
+// *n_members = 0.  Host only, no device.
+int qsim_plan_peek_pass(int n_local_qubits, int n_total_qubits, int n_ops, const int32_t* nq, const int32_t* qubits,
+                        const double* mats, const uint8_t* done, uint64_t avoid_mask, uint64_t hint_mask, uint64_t* tile_mask,
+                        uint64_t* need_mask, int32_t* n_members, int32_t* members) {
+  if (!done || !tile_mask || !n_members || !members) return fail(QSIM_ERR_INVALID, "qsim_plan_peek_pass: null argument");
+  if (n_local_qubits < kTileMinChunk || n_local_qubits > kTileMaxQubits)
+    return fail(QSIM_ERR_INVALID, "qsim_plan_peek_pass: fused passes need %d..%d local qubits", kTileMinChunk, kTileMaxQubits);
+  if (n_total_qubits < n_local_qubits || n_total_qubits > 63) return fail(QSIM_ERR_INVALID, "qsim_plan_peek_pass: bad total qubit count %d", n_total_qubits);
+  if (n_ops < 0 || (n_ops && (!nq || !qubits || !mats))) return fail(QSIM_ERR_INVALID, "bad op list");
+  std::vector<FusedOp> ops;
+  std::vector<int32_t> origin;                 // classified op -> index in the caller's list (identities drop out)
+  std::vector<uint8_t> done_ops;
+  for (int i = 0; i < n_ops; ++i) {
+    if (nq[i] != 1 && nq[i] != 2) return fail(QSIM_ERR_INVALID, "op %d: arity %d", i, nq[i]);
+    for (int j = 0; j < nq[i]; ++j)
+      if (qubits[2 * i + j] < 0 || qubits[2 * i + j] >= n_total_qubits) return fail(QSIM_ERR_INVALID, "op %d: qubit %d out of range", i, qubits[2 * i + j]);
+    if (nq[i] == 2 && qubits[2 * i] == qubits[2 * i + 1]) return fail(QSIM_ERR_INVALID, "op %d: repeated qubit", i);
+    FusedOp o;
+    if (classify_op(nq[i], qubits + 2 * i, mats + 32 * (size_t)i, &o)) { ops.push_back(o); origin.push_back(i); done_ops.push_back(done[i]); }
+  }
+  std::vector<size_t> held;
+  PeekPlan peek;
+  peek.n_total = n_total_qubits;
+  peek.done = done_ops.data();
+  peek.avoid = avoid_mask;
+  peek.tile_mask = peek.need_mask = 0;
+  peek.members = &held;
+  int passes = 0;
+  const TileHint hint = {&hint_mask, 1};
+  const int rc = plan_fused(n_local_qubits, ops, &passes, [](TileArgs&, int, double, bool, bool) { return (int)QSIM_OK; },
+                            hint_mask ? &hint : nullptr, &peek);
+  if (rc) return rc;
+  *tile_mask = peek.tile_mask;
+  if (need_mask) *need_mask = peek.need_mask;
+  *n_members = (int32_t)held.size();
+  for (size_t j = 0; j < held.size(); ++j) members[j] = origin[held[j]];
+  return QSIM_OK;
+}
+
 // Pass counts of ONE op list under several qubit layouts (layouts[l * n_local_qubits + q] = the index bit of logical qubit q
 // in layout l), planned in parallel on the host: the greedy pass builder's result depends on which three qubits live on the
 // line bits (they belong to every tile) -- 17 to 20 passes for the 28-qubit bench circuit -- so an engine that is free to
@@ -887,7 +933,10 @@ static int apply_ops_io_deferred(qsim_chunk* c, int n_ops, const int32_t* nq, co
   if (io->src && !d->fio.src) ++passes;                     // the source cannot be read by a tile pass: unpack pieces
   if (tiles) {
     int p = 0;
-    if ((rc = run_fused(c, ops, &p, &d->fio, n_ops, nq, qubits, mats, &d->passes))) return rc;
+    const TileHint hint = {io->tile_masks, io->n_tiles};
+    if ((rc = run_fused(c, ops, &p, &d->fio, n_ops, nq, qubits, mats, &d->passes, io->n_tiles ? &hint : nullptr))) return rc;
+    d->io.tile_masks = nullptr;                               // (the caller's array: used by the plan above only)
+    d->io.n_tiles = 0;
     passes += p;
     c->own_in_chunk = d->fio.own_in_chunk;
     if (d->fio.src && !d->fio.fused_in) return fail(QSIM_ERR_INVALID, "internal: the first pass did not take the source buffer");
@@ -923,6 +972,10 @@ int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t
   int rc = validate_ops(c, n_ops, nq, qubits, mats);
   if (rc) return rc;
   if (!io) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: io is null");
+  if (io->struct_size != sizeof(qsim_ops_io))
+    return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: io->struct_size is %u, this library's qsim_ops_io has %zu bytes (zero the struct, "
+                "set struct_size = sizeof(qsim_ops_io) and rebuild against this library's include/qsim_hip.h)", io->struct_size, sizeof(qsim_ops_io));
+  if (io->n_tiles < 0 || (io->n_tiles && !io->tile_masks)) return fail(QSIM_ERR_INVALID, "qsim_apply_ops_io: bad tile list");
   auto check_side = [&](const qsim_chunk* b, int m, const int32_t* bits, const char* side) -> int {
     int r = check_chunk(b, "qsim_apply_ops_io");
     if (r) return r;
@@ -981,7 +1034,8 @@ int qsim_apply_ops_io(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t
   }
   if (tiles) {
     int p = 0;
-    if ((rc = run_fused(c, ops, &p, &fio, n_ops, nq, qubits, mats))) return rc;
+    const TileHint hint = {io->tile_masks, io->n_tiles};
+    if ((rc = run_fused(c, ops, &p, &fio, n_ops, nq, qubits, mats, nullptr, io->n_tiles ? &hint : nullptr))) return rc;
     passes += p;
     c->own_in_chunk = fio.own_in_chunk;
     if (fio.src && !fio.fused_in) return fail(QSIM_ERR_INVALID, "internal: the first pass did not take the source buffer");
@@ -1383,6 +1437,7 @@ int qsim_comm_relayout_fused(qsim_comm* cm, qsim_chunk* shard, qsim_chunk* send,
   for (auto& e : cm->ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   qsim_ops_io io;
   std::memset(&io, 0, sizeof io);
+  io.struct_size = sizeof io;
   io.dst = send; io.dst_m = m; io.dst_own = recv; io.own_pattern = p.own;
   for (int i = 0; i < m; ++i) io.dst_bits[i] = local_bits[i];
   io.dst_parts = n_pieces == 1 ? -1 : n_pieces;            // (always the split form: -1 = one piece)
@@ -1408,6 +1463,7 @@ int qsim_comm_relayout_fused(qsim_comm* cm, qsim_chunk* shard, qsim_chunk* send,
   // receive side: `after` is planned now (the links are busy meanwhile) and takes the pieces over as they arrive -- its
   // first pass runs on the tiles whose pieces are there, the rest with the last piece
   std::memset(&io, 0, sizeof io);
+  io.struct_size = sizeof io;
   io.src = recv; io.src_m = m; io.own_pattern = -1;
   for (int i = 0; i < m; ++i) io.src_bits[i] = local_bits[i];
   io.src_parts = n_pieces == 1 ? -1 : n_pieces;

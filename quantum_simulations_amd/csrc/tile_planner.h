@@ -810,8 +810,22 @@ static void emit_groups(const std::vector<FusedOp>& ops, const std::vector<size_
 // runner/engine.py) gets the SAME passes on the new bits instead of whatever the search finds there.  A hint that holds no
 // op (or too many bits) is ignored and the search takes over for that pass.
 struct TileHint { const uint64_t* masks; int n; };
+// Peek mode (qsim_plan_peek_pass, the partition planner of runner/partition_plan.py): the op list lives on `n_total` >= k
+// index bits; the bits >= k are RANK bits of a partitioned state -- never tile bits, never targets (an op that targets one
+// waits, and blocks like any waiting op), but fine as controls and phase bits (a rank applies or skips such an op by its own
+// rank bits).  `done` marks the ops that ran already; the builder chooses the tile of the NEXT pass exactly as it would in a
+// full plan (candidates, look-ahead), reports it with its members and stops: nothing is emitted.
+struct PeekPlan {
+  int n_total;
+  const uint8_t* done;         // per op of ops_in
+  uint64_t avoid;              // index bits the tile should not hold unless its ops need them (the slab bits of a coming re-layout)
+  uint64_t tile_mask;          // out: high tile bits (with the fill)
+  uint64_t need_mask;          // out: ... of which the pass's ops need
+  std::vector<size_t>* members;  // out: indices into ops_in
+};
 template <class Sink>
-static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, Sink&& sink, const TileHint* hint = nullptr) {
+static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, Sink&& sink, const TileHint* hint = nullptr,
+                      PeekPlan* peek = nullptr) {
   const Tuning& tune = tuning();
   std::vector<FusedOp> ops = ops_in;
   if (tune.tile_commute_fuse == 1 || tune.tile_commute_fuse == 4) commute_fuse_1q(&ops, false);
@@ -844,11 +858,19 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
   auto admissible3 = [&](size_t i, u64 bt, u64 bd, u64 bx) {
     return !(qm[i] & bt) && !(tm[i] & bd) && !((qm[i] & ~xm[i]) & bx);
   };
-  const u64 all_qubits = k >= 64 ? ~0ull : ((1ull << k) - 1);
+  const int n_bits = peek ? peek->n_total : k;
+  const u64 all_qubits = n_bits >= 64 ? ~0ull : ((1ull << n_bits) - 1);
+  const u64 rank_bits = all_qubits & ~(k >= 64 ? ~0ull : ((1ull << k) - 1));   // (peek mode only: no tile bit, no target)
   const bool lookahead = tune.plan_lookahead >= 0 ? tune.plan_lookahead != 0 : k >= 24;
   size_t remaining = n_ops;
   size_t first = 0;
   *n_passes = 0;
+  if (peek) {
+    remaining = 0;
+    for (size_t i = 0; i < n_ops; ++i) { done[i] = peek->done[i] != 0; remaining += !done[i]; }
+    peek->tile_mask = peek->need_mask = 0;
+    peek->members->clear();
+  }
   // How far behind `first` a pass looks for ops (counted in ops not yet done).  The scans below end early once every
   // qubit is blocked for everything (`bt`), which never happens while some qubit is used only as a control, phase bit or
   // X target (a GHZ root, a phase-estimation ancilla, an idle qubit): every scan then walked the whole remaining list --
@@ -937,7 +959,7 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
         if (++seen > scan_window) break;
         bool ok = admissible3(i, bt, bd, bx);
         const u64 extra = need[i] & ~mask;
-        if (ok && n_forced + (int)claimed.size() + __builtin_popcountll(extra) > cap) ok = false;
+        if (ok && (n_forced + (int)claimed.size() + __builtin_popcountll(extra) > cap || (extra & rank_bits))) ok = false;
         if (!ok) { bt |= tm[i] & ~xm[i]; bx |= xm[i]; bd |= qm[i] & ~tm[i]; if (bt == all_qubits) break; continue; }
         for (u64 e = extra; e; e &= e - 1) claimed.push_back(__builtin_ctzll(e));
         mask |= extra;
@@ -1004,6 +1026,18 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
     for (int b = low; b < k; ++b) if ((best_mask >> b) & 1) high.push_back(b);
     std::vector<size_t> members;
     holds(best_mask, &members);
+    if (peek) {
+      // (everything that is left may be waiting for a rank bit: an empty pass is an answer here, not an error)
+      if (members.empty()) { *n_passes = 0; return QSIM_OK; }
+      u64 needed = 0;
+      for (size_t i : members) needed |= need[i];
+      std::vector<int> kept;
+      for (int b : high) if ((needed >> b) & 1) kept.push_back(b);
+      for (int b = low; (int)kept.size() < cap && b < k; ++b)                        // the fill: not the bits to avoid
+        if (!((peek->avoid >> b) & 1) && std::find(kept.begin(), kept.end(), b) == kept.end()) kept.push_back(b);
+      high = kept;
+      peek->need_mask = needed;
+    }
     if (members.empty()) return fail(QSIM_ERR_INVALID, "internal: fused planner made no progress");
     // fill the tile with the lowest unused bits so it always has T bits
     for (int b = low; (int)high.size() < cap && b < k; ++b)
@@ -1056,6 +1090,14 @@ static int plan_fused(int k, const std::vector<FusedOp>& ops_in, int* n_passes, 
         done[members[mi]] = 1; --remaining; ++n_emitted;
       }
     if (!n_emitted) return fail(QSIM_ERR_INVALID, "internal: fused planner emitted nothing");
+    if (peek) {
+      // the ops whose records fit the pass (a rank runs this list without the ops its rank bits switch off and with the
+      // rank-bit predicates gone: never more records than counted here)
+      for (int b : high) peek->tile_mask |= 1ull << b;
+      for (size_t mi = 0; mi < members.size(); ++mi) if (emitted[mi]) peek->members->push_back(members[mi]);
+      *n_passes = 1;
+      return QSIM_OK;
+    }
 #ifdef QSIM_PROBES
     if (tune.debug_skip_gates) {                   // profiling aid: load -> LDS -> store only (WRONG results)
       groups.resize(1);

@@ -176,7 +176,7 @@ class DeviceChunk:
         return lib.qsim_last_pass_count(self._h) if fused else len(ops)
 
     # ---- sync / reductions / timing -------------------------------------------------
-    def apply_ops_io(self, ops, src=None, dst=None, parts: int = 0, src_parts: int = 0) -> int:
+    def apply_ops_io(self, ops, src=None, dst=None, parts: int = 0, src_parts: int = 0, tiles=None) -> int:
         """`apply_ops` with a re-layout fused into its ends (qsim_apply_ops_io): `src` = (chunk, bits): the state
         is read from that chunk in the slab layout of `pack_all` over `bits`; `dst` = (chunk, bits, own_chunk,
         own_pattern): it is left in `chunk` in slab layout, slab `own_pattern` (>= 0) in `own_chunk` -- which may be the
@@ -185,10 +185,15 @@ class DeviceChunk:
         while the later pieces are still computed (negative: no 2^20-amplitude floor on a piece, for tests).
         `src_parts` (with `src`): the source arrives in the pieces of the same rule: this call only plans; announce every
         piece with `load_part(j)` once its transfer is ordered on this chunk's stream -- the first pass starts on the
-        tiles whose pieces are there, the rest runs with the last piece."""
+        tiles whose pieces are there, the rest runs with the last piece.  `tiles`: uint64 masks, the high tile bits of the
+        first passes named by the caller (qsim_ops_io::tile_masks; as in `apply_ops_tiled`)."""
         nq, qs, mats = pack_ops(ops) if not (isinstance(ops, tuple) and len(ops) == 3 and isinstance(ops[0], np.ndarray)) else ops
         io = _lib.OpsIo()
         keep = []
+        if tiles is not None and len(tiles):
+            tm = np.ascontiguousarray(tiles, dtype=np.uint64)
+            io.n_tiles, io.tile_masks = len(tm), tm.ctypes.data
+            keep.append(tm)
         if src is not None:
             chunk, bits = src
             io.src, io.src_m = chunk._h, len(bits)

@@ -99,18 +99,21 @@ class HipShardBackend:
         self.torch.cuda.synchronize(self.device)
 
     # ---- arithmetic -----------------------------------------------------------------
-    def apply_ops(self, ops, src=None, dst=None, parts: int = 0, src_parts: int = 0) -> int:
+    def apply_ops(self, ops, src=None, dst=None, parts: int = 0, src_parts: int = 0, tiles=None) -> int:
         """HBM passes made.  src = (buffer, bits): the shard is read from that buffer in slab layout; dst = (buffer,
         bits, own_buffer, own_pattern): it is left there in slab layout (qsim_apply_ops_io: the re-layout's pack /
         unpack ride in the last / first fused pass).  parts (with dst): split form -- the slabs are stored piece by piece
         by `store_part(j)` for every piece of `pending_parts()`.  src_parts (with src): the source is still arriving in
-        pieces: nothing runs until `load_part(j)` announces them, the first pass piece by piece."""
+        pieces: nothing runs until `load_part(j)` announces them, the first pass piece by piece.  tiles: the high tile bits
+        of the first passes as the partition planner chose them (uint64 masks)."""
         st = self.chunk("state")
         if src is None and dst is None:
+            if tiles is not None and len(tiles) and len(ops) >= 2:
+                return st.apply_ops_tiled(ops, tiles)
             return st.apply_ops(ops)
         return st.apply_ops_io(ops, src=(self.chunk(src[0]), src[1]) if src else None,
                                dst=(self.chunk(dst[0]), dst[1], self.chunk(dst[2]), dst[3]) if dst else None, parts=parts,
-                               src_parts=src_parts)
+                               src_parts=src_parts, tiles=tiles)
 
     def own_slab_in_state(self) -> bool:
         """The last `apply_ops` with a `dst` whose own-slab buffer was the source buffer left that slab in "state" (one
@@ -248,7 +251,7 @@ class DryBackend:
     def sync(self) -> None:
         pass
 
-    def apply_ops(self, ops, src=None, dst=None, parts: int = 0, src_parts: int = 0) -> int:
+    def apply_ops(self, ops, src=None, dst=None, parts: int = 0, src_parts: int = 0, tiles=None) -> int:
         self._loads = len(split_pieces(self.k, len(src[1]), src_parts)) if (src is not None and src_parts) else 0
         for side in (src, dst):
             if side is not None:
@@ -317,7 +320,7 @@ class PlanningBackend(DryBackend):
         self.passes = 0
         self.record: list | None = None  # (tools/shard_compute_probe.py: the op lists as the rank would run them)
 
-    def _plan(self, ops) -> tuple:
+    def _plan(self, ops, tiles=None) -> tuple:
         """(passes, their model weight, tile bits of the last pass) of the fused plan of `ops` (tile passes possible)"""
         import ctypes as C
 
@@ -326,12 +329,14 @@ class PlanningBackend(DryBackend):
         nq, qubits, mats = pack_ops(ops)
         lib = _lib.load()
         count = C.c_int32()
-        args = (self.k, len(nq), nq.ctypes.data_as(C.c_void_p), qubits.ctypes.data_as(C.c_void_p), mats.ctypes.data_as(C.c_void_p))
+        tm = np.ascontiguousarray(tiles if tiles is not None else [], dtype=np.uint64)
+        args = (self.k, len(nq), nq.ctypes.data_as(C.c_void_p), qubits.ctypes.data_as(C.c_void_p), mats.ctypes.data_as(C.c_void_p),
+                len(tm), tm.ctypes.data_as(C.c_void_p) if len(tm) else None)
         images = self._images
-        _lib.check(lib.qsim_plan_ops(*args, images.ctypes.data_as(C.c_void_p), images.nbytes, C.byref(count)))
+        _lib.check(lib.qsim_plan_ops_tiled(*args, images.ctypes.data_as(C.c_void_p), images.nbytes, C.byref(count)))
         if count.value > len(images):    # (a buffer too small only reports the count)
             images = self._images = np.zeros((2 * count.value, 4096), dtype=np.uint8)
-            _lib.check(lib.qsim_plan_ops(*args, images.ctypes.data_as(C.c_void_p), images.nbytes, C.byref(count)))
+            _lib.check(lib.qsim_plan_ops_tiled(*args, images.ctypes.data_as(C.c_void_p), images.nbytes, C.byref(count)))
         weight, last = 0.0, set()
         for p in range(count.value):     # (pass image = the kernel-argument block: T at byte 12, the tile's high bits from 16)
             T = int(images[p, 12:16].view("<i4")[0])
@@ -339,7 +344,7 @@ class PlanningBackend(DryBackend):
             weight += self._tile_layout.tile_cost(self.model, sorted(last)) / self.model_ref if self.model is not None else 1.0
         return count.value, weight, last
 
-    def apply_ops(self, ops, src=None, dst=None, parts: int = 0, src_parts: int = 0) -> int:
+    def apply_ops(self, ops, src=None, dst=None, parts: int = 0, src_parts: int = 0, tiles=None) -> int:
         self._loads = len(split_pieces(self.k, len(src[1]), src_parts)) if (src is not None and src_parts) else 0
         for side in (src, dst):
             if side is not None:
@@ -350,13 +355,14 @@ class PlanningBackend(DryBackend):
         if self.record is not None and ops:
             self.record.append(ops)
         if ops and 8 <= self.k <= 35:
-            passes, weight, last = self._plan(ops)
+            passes, weight, last = self._plan(ops, tiles)
         else:                            # (shards too small for tile passes: one launch per gate)
             passes, weight, last = len(ops), float(len(ops)), None
         tiles = last is not None and passes > 0
         fused_in = src is not None and tiles and min(src[1]) >= 3
         fused_out = dst is not None and tiles and min(dst[1]) >= 3 and not (set(dst[1]) & last)
         extra = int(src is not None and not fused_in) + int(dst is not None and not fused_out)
+        self.last_extra = extra
         # (qsim_apply_ops_io_own_slab: ONE pass reads the source and stores the slabs)
         self._own_in_state = bool(src is not None and dst is not None and dst[2] == src[0] and fused_in and fused_out and passes == 1)
         self.local_passes += 1
@@ -376,7 +382,7 @@ class PlanningBackend(DryBackend):
 class DistributedEngine:
     def __init__(self, n_qubits: int, world: int, rank: int, local_rank: int = 0,
                  mode: str = "fused", backend=None, staging: bool = True,
-                 staging_method: str = "belady", init_process_group: bool = True,
+                 staging_method: str = "tiles", init_process_group: bool = True,
                  relayout_pieces: int = 4, min_piece_qubits: int = 20, fuse_relayout: bool = True,
                  rehearsal: bool = False, exchange: str = "torch", layout: str = "auto"):
         import torch
@@ -393,6 +399,10 @@ class DistributedEngine:
             raise ValueError(f"{n_qubits} qubits on {world} ranks leave {max(self.k, 0)} local qubit(s): at least 2 are needed "
                              "(use fewer ranks)")
         self.mode, self.staging, self.staging_method = mode, staging, staging_method
+        self.tiles_min_ops = 0       # staging method "tiles": 0 = search the thin-pass threshold (plan_partition_best)
+        self.plan_threads = 8
+        self._plan_effort_high = False
+        self.use_tile_hints = True
         # rehearsal (explicit argument; bench.py --rehearsal): several ranks share the visible GPU(s), each with its shard
         # in HBM and the real HIP kernels, and exchange through host-staged gloo -- RCCL refuses two ranks on one
         # device.  `self.exchange` names what carries the transfers and is printed in every bench line.
@@ -446,6 +456,7 @@ class DistributedEngine:
         self._passes = self.last_passes = 0
         self.home_moves = 0                        # times "state" and "buf1" traded names (one-pass op list between two re-layouts)
         self._pending: list = []
+        self._pending_tiles: list = []             # tile masks the planner named for the passes of the queued ops
         # Re-layout fused with the neighbouring local passes (round 3): the last fused pass before an exchange stores
         # its tiles straight into the send buffer in slab order and the first one after it loads them from the
         # receive buffer -- no separate pack / unpack pass of the shard.  `_state_in` = (buffer, local bits) while
@@ -554,20 +565,23 @@ class DistributedEngine:
         the first pass runs on the tiles whose pieces are there while the later pieces are on the links.  `dst` / `parts`:
         the slab-storing end of the next re-layout."""
         src = self._state_in
+        kw = {}
+        if self._pending_tiles:          # (the partition planner's tiles for this op list: staging method "tiles")
+            kw["tiles"], self._pending_tiles = np.array(self._pending_tiles, dtype=np.uint64), []
         if src is None:
             if dst is None:
                 if ops:
-                    self._passes += self.backend.apply_ops(ops) or 0
+                    self._passes += self.backend.apply_ops(ops, **kw) or 0
             else:
-                self._passes += self.backend.apply_ops(ops, dst=dst, parts=parts) or 0
+                self._passes += self.backend.apply_ops(ops, dst=dst, parts=parts, **kw) or 0
             return
         self._state_in = None
         if self._inflight is None:
-            self._passes += self.backend.apply_ops(ops, src=src, dst=dst, parts=parts) or 0
+            self._passes += self.backend.apply_ops(ops, src=src, dst=dst, parts=parts, **kw) or 0
             return
         posted, timer = self._inflight
         self._inflight = None
-        self._passes += self.backend.apply_ops(ops, src=src, dst=dst, parts=parts, src_parts=self._split_parts()) or 0
+        self._passes += self.backend.apply_ops(ops, src=src, dst=dst, parts=parts, src_parts=self._split_parts(), **kw) or 0
         for j, pst in enumerate(posted):
             self._finish(pst)
             self.backend.load_part(j)
@@ -593,6 +607,7 @@ class DistributedEngine:
     def init_zero_state(self) -> None:
         self._drain_inflight()
         self._pending = []
+        self._pending_tiles = []
         self._state_in = None
         self.backend.init_zero(self.rank == 0)
         self.l2p_planned = list(range(self.n))
@@ -621,13 +636,43 @@ class DistributedEngine:
         return permute_state(full, self.l2p)
 
     # ---- planning --------------------------------------------------------------------------
+    def _tiles_method(self) -> bool:
+        """Staging method "tiles" applies: shards large enough for tile passes (the planner is the library's pass builder)."""
+        return bool(self.staging and self.staging_method == "tiles" and 8 <= self.k <= 35 and self.n <= 63)
+
+    def _fused_ops(self, cd: dict, l2p: list) -> list:
+        """The circuit as an op list on the index bits of layout `l2p`, runs of 1q gates fused (fusion.py:41-81)."""
+        from quantum_simulations_amd.circuit.fusion import fuse_1q_ops
+        return fuse_1q_ops([([l2p[q] for q in g["qubits"]], gate_table.gate_matrix(g["gate"], g["params"])) for g in cd["gates"]])
+
+    def _packed_ops(self, cd: dict):
+        """`_fused_ops` in logical labels, packed once per circuit for the partition planner (relabelled per layout)."""
+        from quantum_simulations_amd.runner.partition_plan import PackedOps
+        key = id(cd)
+        if getattr(self, "_packed_key", None) != key:
+            self._packed, self._packed_key, self._packed_cd = PackedOps(self._fused_ops(cd, list(range(self.n))), self.n), key, cd
+        return self._packed
+
     def _steps_from(self, cd: dict, l2p: list[int]):
         """Plan `cd` for a state whose logical qubit q currently sits at physical bit l2p[q]."""
         relabeled = {"number_of_qubits": self.n,
                      "gates": [{"qubits": [l2p[q] for q in g["qubits"]], "gate": g["gate"],
                                 "params": g["params"]} for g in cd["gates"]]}
-        if self.staging and self.k >= 2:   # (staging cannot hold a 2-qubit gate in fewer than 2 local qubits)
-            steps, moved = atlas_stages(relabeled, self.k, method=self.staging_method,
+        if self._tiles_method():
+            # stage boundaries and tile passes planned together (runner/partition_plan.py)
+            from quantum_simulations_amd.runner.partition_plan import MIN_OPS_CHOICES, plan_partition, plan_partition_best
+            ops = self._packed_ops(cd).relabeled(l2p)
+            if self.tiles_min_ops:
+                res = plan_partition(ops, self.n, self.k, min_ops=self.tiles_min_ops, relayout_cost=self.RELAYOUT_PASSES)
+            else:
+                # (plans that run a few times search less: planning is host time the caller waits for)
+                choices = MIN_OPS_CHOICES if self._plan_effort_high else (16, 24)
+                res = plan_partition_best(ops, self.n, self.k, choices=choices, relayout_cost=self.RELAYOUT_PASSES, threads=self.plan_threads)
+            self.last_partition_plan = res
+            steps, moved = res["steps"], res["moved"]
+        elif self.staging and self.k >= 2:   # (staging cannot hold a 2-qubit gate in fewer than 2 local qubits)
+            # ("tiles" on shards too small for tile passes: the stage-by-stage method it replaces)
+            steps, moved = atlas_stages(relabeled, self.k, method="belady" if self.staging_method == "tiles" else self.staging_method,
                                         strict_order=True)
         else:
             steps, moved = batch_levels(levelize(relabeled), self.k), list(range(self.n))
@@ -688,6 +733,57 @@ class DistributedEngine:
                                        "relayouts": scored[best][2], "index": best}}
         return cands[best]
 
+    LAYOUT_MIN_REPEATS = 8          # layout "auto": plans for fewer executions try 4 start layouts, not 16 (the search is host time)
+
+    def choose_initial_layout_tiles(self, cd: dict, repeats: int = 1, n_candidates: int | None = None, seed: int = 20260504) -> list:
+        """Staging method "tiles": l2p for a state that is still |0..0>.  Candidates: the identity, and assignments that put
+        the p qubits whose FIRST use as a target comes last on the rank bits (Belady at time zero) with the other qubits
+        in random order (which three sit on the line bits, members of every tile, moves the pass count).  Each is priced by
+        the partition planner itself -- passes + re-layouts in pass units of the first execution, and of a second one from
+        the layout the first leaves behind when the plan will be repeated -- in parallel threads.  The planner names its
+        tiles to the library, so what is priced is what every rank runs: no twin execution, no collective.  Deterministic."""
+        import time
+
+        from quantum_simulations_amd.runner.partition_plan import plan_partition, planning_pool
+        t0 = time.perf_counter()
+        n, k, p = self.n, self.k, self.p
+        if n_candidates is None:
+            n_candidates = 16 if self._plan_effort_high else 1
+        packed = self._packed_ops(cd)
+        first = [1 << 60] * n
+        for i, tg in enumerate(packed.targets):
+            for q in tg:
+                first[q] = min(first[q], i)
+        far = sorted(range(n), key=lambda q: (-first[q], -q))[:p]
+        rng = np.random.default_rng(seed)
+        cands = [list(range(n))]
+        for c in range(n_candidates):
+            rest = [int(q) for q in (rng.permutation(n) if c else np.arange(n)) if q not in far]
+            l2p = [0] * n
+            for i, q in enumerate(rest):
+                l2p[q] = i
+            for i, q in enumerate(sorted(far)):
+                l2p[q] = k + i
+            cands.append(l2p)
+
+        def price(l2p):
+            costs, first_exec = [], None
+            for _ in range(2 if repeats > 1 else 1):
+                r = plan_partition(packed.relabeled(l2p), n, k, min_ops=self.tiles_min_ops or 24, relayout_cost=self.RELAYOUT_PASSES)
+                costs.append(r["cost"])
+                first_exec = first_exec or (r["passes"], r["relayouts"])
+                l2p = [r["moved"][l2p[q]] for q in range(n)]
+            later = costs[-1]
+            return (costs[0] + (max(1, repeats) - 1) * later) / max(1, repeats), first_exec[0], first_exec[1]
+        scored = list(planning_pool(self.plan_threads).map(price, cands)) if self.plan_threads > 1 else [price(c) for c in cands]
+        best = min(range(len(cands)), key=lambda i: (scored[i][0], i))
+        self.layout_info = {"candidates": len(cands), "executions_planned_for": max(1, repeats), "method": "tiles",
+                            "identity": {"cost_max_over_ranks": round(scored[0][0], 2), "passes_this_rank": scored[0][1], "relayouts": scored[0][2]},
+                            "chosen": {"cost_max_over_ranks": round(scored[best][0], 2), "passes_this_rank": scored[best][1],
+                                       "relayouts": scored[best][2], "index": best},
+                            "search_seconds": round(time.perf_counter() - t0, 3)}
+        return cands[best]
+
     def plan(self, circuit_dict: dict, repeats: int = 1) -> Plan:
         """Step lists for `repeats` successive executions from the engine's current layout.  COLLECTIVE when it is the first
         plan of a freshly initialised state and the engine searches the initial layout (every rank must call it: rank 0's
@@ -695,11 +791,18 @@ class DistributedEngine:
         cd = validate_circuit_dict(circuit_dict)
         if cd["number_of_qubits"] != self.n:
             raise ValueError(f"circuit has {cd['number_of_qubits']} qubits, engine has {self.n}")
+        self._plan_effort_high = repeats >= self.LAYOUT_MIN_REPEATS or self.layout == "search"
         if self._fresh:
             # (once per initialised state: a second plan made before the first one runs keeps this layout, so both stay valid)
             self._fresh = False
             if self.world > 1 and self.k >= 2 and (self.layout == "search" or (self.layout == "auto" and self.k >= 20)):
-                self.l2p_planned = self.choose_initial_layout(cd, repeats=max(1, repeats))
+                if self._tiles_method():
+                    self.l2p_planned = self.choose_initial_layout_tiles(cd, repeats=max(1, repeats))
+                else:
+                    import time
+                    t0 = time.perf_counter()
+                    self.l2p_planned = self.choose_initial_layout(cd, repeats=max(1, repeats))
+                    self.layout_info["search_seconds"] = round(time.perf_counter() - t0, 3)
         executions, mappings, starts = [], [], []
         l2p = list(self.l2p_planned)
         for _ in range(max(1, repeats)):
@@ -743,6 +846,8 @@ class DistributedEngine:
         rank bit (and back), so every op is classified by where its qubits actually are."""
         k = self.k
         self._fresh = False              # (the state is no longer |0..0>: no later plan may pick another layout for it)
+        if step.get("tile_masks") and self.use_tile_hints:
+            self._pending_tiles += [int(m) for m in step["tile_masks"]]
         batch = []
         for qs, U in step["local_ops"]:
             aq = self._actual(qs)

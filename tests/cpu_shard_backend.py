@@ -73,7 +73,7 @@ class CpuShardBackend:
     def sync(self) -> None:
         pass
 
-    def apply_ops(self, ops, src=None, dst=None, parts: int = 0, src_parts: int = 0) -> None:
+    def apply_ops(self, ops, src=None, dst=None, parts: int = 0, src_parts: int = 0, tiles=None) -> None:
         """src / dst: the fused re-layout ends of qsim_apply_ops_io (runner/distributed.py), restated with the slab
         helpers below: read the shard from a receive buffer in slab layout / leave it in slab layout for the exchange
         (own slab in the receive buffer).  src_parts: the source is still arriving: nothing happens until `load_part`

@@ -93,6 +93,8 @@ def _worker(rank, world, port, n, staging_modes, errors, moves=None):
                     (orc.apply_1q if len(g["qubits"]) == 1 else orc.apply_2q)(want2, *g["qubits"], U)
                 err2 = float(np.max(np.abs(eng.state_vector() - want2)))
                 assert err2 < 1e-12, f"{name} repeat staging={staging}/{method}: {err2}"
+                if method == "tiles" and n - p >= 8:     # (the partition planner really planned this run)
+                    assert eng.last_partition_plan["passes"] >= 1 and eng.last_partition_plan["segments"]
             if moves is not None:
                 moves.put(eng.home_moves)
             eng.backend.close()
@@ -155,6 +157,15 @@ def test_world8_gloo():
 def test_world8_gloo_larger_shards():
     """8 ranks x 7 local qubits: three-qubit re-layouts (7/8 of a shard to seven peers) through the fused path."""
     _run(8, 10, [(True, "belady"), (False, "heuristic")], expect_home_moves=True)
+
+
+def test_tiles_staging_world2_4_8_gloo():
+    """Staging method "tiles" (stage boundaries and tile passes planned together, runner/partition_plan.py) needs shards of
+    >= 8 local qubits (the library's pass builder plans them): 2 / 4 / 8 ranks, every circuit family, two executions, with
+    and without fused re-layouts, searched and identity start layouts -- amplitudes against the oracle at 1e-12."""
+    _run(2, 10, [(True, "tiles"), (True, "tiles", False)])
+    _run(4, 10, [(True, "tiles"), (True, "tiles")])
+    _run(8, 11, [(True, "tiles"), (True, "tiles", False)])
 
 
 def test_two_local_qubits_is_the_minimum():
