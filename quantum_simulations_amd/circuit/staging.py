@@ -16,10 +16,15 @@ On the MI355X build the step list *is* the multi-GPU schedule:
     are global need no exchange on the GPU (rank-bit phase) -- the reference
     executes them as butterflies (staging.py:67-72), this build does not.
 
-`method="ilp"` needs PuLP, which this image does not have; it raises ImportError
-exactly like the reference does without PuLP (staging.py:203-204).  `method="belady"` is this
-build's addition (farthest-next-use stage sets, fewer and wider re-layouts); the multi-GPU
-engine uses it by default.
+`method="ilp"` is the reference's formulation (staging.py:176-315: binaries x[s][q], y[g][s],
+transition cost d[s][q], binary search on the stage count, 30 s per solve) restated on
+`scipy.optimize.milp` (HiGHS): PuLP, which the reference solves it with, is not in this image.
+Without scipy it raises the reference's ImportError (staging.py:203-204).  The stage SETS an
+ILP returns are one optimum among several and cannot be compared with the reference's CBC run
+(parity unpinned for the sets; every schedule is checked against the oracle's amplitudes).
+`method="belady"` is this build's addition (farthest-next-use stage sets, fewer and wider
+re-layouts); the multi-GPU engine plans stages and tile passes together instead
+(runner/partition_plan.py) and falls back to "belady" on shards too small for tile passes.
 """
 from __future__ import annotations
 
@@ -36,6 +41,13 @@ try:  # optional, reference staging.py:49-53
     HAS_PULP = True
 except ImportError:
     HAS_PULP = False
+try:  # the solver this build uses for method="ilp"
+    from scipy.optimize import Bounds, LinearConstraint, milp
+    from scipy.sparse import csr_array
+    HAS_MILP = True
+except ImportError:  # pragma: no cover - scipy ships with the image
+    HAS_MILP = False
+ILP_TIME_LIMIT_S = 30.0        # per solve, as the reference (staging.py:305)
 
 # Diagonal ("sparse") gates: none of their qubits has to be local (Atlas is_sparse()).
 _DIAGONAL_GATES = frozenset({"Z", "S", "T", "CZ", "CR"})
@@ -242,6 +254,90 @@ def _compute_local_qubits_belady(gates: list[dict], n: int, k: int) -> list[set[
         stages.append(set(local))
 
 
+# ------------------------------------------------------------------- ILP (Atlas 3.2)
+def _try_ilp(gates, n: int, k: int, n_stages: int, ni_qubits, predecessors, time_limit: float):
+    """The reference's `_try_ilp` (staging.py:243-315) for a given stage count, on scipy's MILP interface.
+    Variables, in this order: x[s][q] (qubit q local in stage s), y[g][s] (gate g runs in stage s), both binary, and
+    d[s][q] >= |x[s][q] - x[s+1][q]| continuous.  Returns the stage sets of an optimal solution or None (infeasible or
+    not proven optimal within the time limit -- the reference treats both alike)."""
+    S, G, Q = n_stages, len(gates), n
+    nx, ny, nd = S * Q, G * S, (S - 1) * Q
+    X = lambda s, q: s * Q + q                     # noqa: E731
+    Y = lambda g, s: nx + g * S + s                # noqa: E731
+    D = lambda s, q: nx + ny + s * Q + q           # noqa: E731
+    rows, cols, vals, lo, hi = [], [], [], [], []
+    r = 0
+
+    def add(entries, lower, upper):
+        nonlocal r
+        for c, v in entries:
+            rows.append(r)
+            cols.append(c)
+            vals.append(v)
+        lo.append(lower)
+        hi.append(upper)
+        r += 1
+    for g in range(G):                             # 1) every gate in exactly one stage
+        add([(Y(g, s), 1.0) for s in range(S)], 1.0, 1.0)
+    for g in range(G):                             # 2) a predecessor runs in an earlier or the same stage
+        for pg in predecessors[g]:
+            for s in range(S):
+                add([(Y(pg, sp), 1.0) for sp in range(s + 1)] + [(Y(g, s), -1.0)], 0.0, np.inf)
+    for g in range(G):                             # 3) non-insular qubits are local in the gate's stage
+        for q in ni_qubits[g]:
+            for s in range(S):
+                add([(Y(g, s), 1.0), (X(s, q), -1.0)], -np.inf, 0.0)
+    for s in range(S):                             # 4) exactly k local qubits per stage
+        add([(X(s, q), 1.0) for q in range(Q)], float(k), float(k))
+    for s in range(S - 1):                         # d >= +-(x[s] - x[s+1])
+        for q in range(Q):
+            add([(D(s, q), 1.0), (X(s, q), -1.0), (X(s + 1, q), 1.0)], 0.0, np.inf)
+            add([(D(s, q), 1.0), (X(s, q), 1.0), (X(s + 1, q), -1.0)], 0.0, np.inf)
+    nvar = nx + ny + nd
+    A = csr_array((vals, (rows, cols)), shape=(r, nvar))
+    c = np.zeros(nvar)
+    c[nx + ny:] = 1.0                              # total transition cost
+    integrality = np.zeros(nvar)
+    integrality[:nx + ny] = 1
+    ub = np.ones(nvar)
+    ub[nx + ny:] = np.inf
+    res = milp(c, constraints=LinearConstraint(A, lo, hi), integrality=integrality, bounds=Bounds(np.zeros(nvar), ub),
+               options={"time_limit": time_limit, "disp": False})
+    if res.status != 0 or res.x is None:           # (0 = optimal; 1 = time / iteration limit, 2 = infeasible ...)
+        return None
+    return [{q for q in range(Q) if res.x[X(s, q)] > 0.5} for s in range(S)]
+
+
+def _compute_local_qubits_ilp(gates: list[dict], n: int, k: int, time_limit: float | None = None) -> list[set[int]]:
+    """Stage sets by integer programming: the fewest stages for which the ILP is feasible (binary search between 1 and the
+    heuristic's stage count, as the reference does: staging.py:176-240), and among those the assignment with the fewest
+    qubits changing sides between consecutive stages."""
+    if not HAS_MILP:
+        raise ImportError("PuLP is required for method='ilp'. pip install pulp")
+    if not gates:
+        return [set(range(min(k, n)))]
+    time_limit = ILP_TIME_LIMIT_S if time_limit is None else time_limit
+    ni_qubits = [non_insular_qubits(g) for g in gates]
+    last_on: dict[int, int] = {}
+    predecessors: list[list[int]] = [[] for _ in gates]
+    for gi, g in enumerate(gates):
+        for q in g["qubits"]:
+            if q in last_on:
+                predecessors[gi].append(last_on[q])
+            last_on[q] = gi
+    heuristic = _compute_local_qubits_heuristic(gates, n, k)
+    lo_s, hi_s = 1, min(len(gates), len(heuristic))
+    best = None
+    while lo_s <= hi_s:
+        mid = (lo_s + hi_s) // 2
+        found = _try_ilp(gates, n, k, mid, ni_qubits, predecessors, time_limit)
+        if found is not None:
+            best, hi_s = found, mid - 1
+        else:
+            lo_s = mid + 1
+    return best if best is not None else heuristic
+
+
 # --------------------------------------------------------------- greedy (legacy)
 def _greedy_stages(gates: list[dict], n: int, k: int, lookahead: int):
     """Gate-by-gate: on the first non-local gate, re-layout to the k most frequent
@@ -283,7 +379,7 @@ def _greedy_stages(gates: list[dict], n: int, k: int, lookahead: int):
 def atlas_stages(circuit_dict: dict, k: int, method: str = "heuristic",
                  lookahead: int = 200, strict_order: bool = False) -> tuple[list[dict], list[int]]:
     """Circuit -> (steps, log_to_phys).  `k` = log2(shard amplitudes).  `strict_order` (this
-    build's addition, see `_local_sets_to_steps`) only affects method="heuristic"."""
+    build's addition, see `_local_sets_to_steps`) affects methods "heuristic" and "ilp"."""
     cd = validate_circuit_dict(circuit_dict)
     n = cd["number_of_qubits"]
     gates = cd["gates"]
@@ -292,10 +388,7 @@ def atlas_stages(circuit_dict: dict, k: int, method: str = "heuristic",
     if method == "greedy":
         return _greedy_stages(gates, n, k, lookahead)
     if method == "ilp":
-        if not HAS_PULP:
-            raise ImportError("PuLP is required for method='ilp'. pip install pulp")
-        raise NotImplementedError("ILP staging is out of scope of the MI355X build "
-                                  "(SURVEY 2 row 2); use 'heuristic' or 'greedy'")
+        return _local_sets_to_steps(gates, n, k, _compute_local_qubits_ilp(gates, n, k), strict_order=strict_order)
     if method == "belady":   # this build's xGMI-oriented method; always dependency-safe ordering
         return _local_sets_to_steps(gates, n, k, _compute_local_qubits_belady(gates, n, k),
                                     strict_order=True)
