@@ -318,7 +318,7 @@ class PlanningBackend(DryBackend):
         self._images = np.zeros((64, 4096), dtype=np.uint8)
         self.weight = 0.0                # model-weighted passes since the last reset
         self.passes = 0
-        self.record: list | None = None  # (tools/shard_compute_probe.py: the op lists as the rank would run them)
+        self.record: list | None = None  # (tools/shard_compute_probe.py: (op list, named tiles) as the rank would run them)
 
     def _plan(self, ops, tiles=None) -> tuple:
         """(passes, their model weight, tile bits of the last pass) of the fused plan of `ops` (tile passes possible)"""
@@ -353,7 +353,7 @@ class PlanningBackend(DryBackend):
             self._parts = split_pieces(self.k, len(dst[1]), parts)
         ops = list(ops)
         if self.record is not None and ops:
-            self.record.append(ops)
+            self.record.append((ops, None if tiles is None else [int(m) for m in tiles]))
         if ops and 8 <= self.k <= 35:
             passes, weight, last = self._plan(ops, tiles)
         else:                            # (shards too small for tile passes: one launch per gate)
@@ -402,6 +402,7 @@ class DistributedEngine:
         self.tiles_min_ops = 0       # staging method "tiles": 0 = search the thin-pass threshold (plan_partition_best)
         self.plan_threads = 8
         self._plan_effort_high = False
+        self.place_slots = True      # staging method "tiles", fresh state: local slots placed by the tile-cost model
         self.use_tile_hints = True
         # rehearsal (explicit argument; bench.py --rehearsal): several ranks share the visible GPU(s), each with its shard
         # in HBM and the real HIP kernels, and exchange through host-staged gloo -- RCCL refuses two ranks on one
@@ -792,6 +793,7 @@ class DistributedEngine:
         if cd["number_of_qubits"] != self.n:
             raise ValueError(f"circuit has {cd['number_of_qubits']} qubits, engine has {self.n}")
         self._plan_effort_high = repeats >= self.LAYOUT_MIN_REPEATS or self.layout == "search"
+        was_fresh = self._fresh and self.layout != "identity"
         if self._fresh:
             # (once per initialised state: a second plan made before the first one runs keeps this layout, so both stay valid)
             self._fresh = False
@@ -810,6 +812,21 @@ class DistributedEngine:
             steps, l2p = self._steps_from(cd, l2p)
             executions.append(steps)
             mappings.append(list(l2p))
+        if was_fresh and self.place_slots and self._tiles_method() and self.k >= 26:
+            # |0..0> looks the same under every assignment of qubits to index bits: the local slots of the whole chain of
+            # executions are put on the index bits whose tiles have the best DRAM pattern (partition_plan.place_slots)
+            import time
+
+            from quantum_simulations_amd.runner.partition_plan import place_slots
+            t0 = time.perf_counter()
+            sigma, before, after = place_slots(executions, self.k)
+            if sigma is not None:
+                mp = lambda b: sigma.get(b, b)                           # noqa: E731
+                starts = [[mp(b) for b in m] for m in starts]
+                mappings = [[mp(b) for b in m] for m in mappings]
+                self.l2p_planned = list(starts[0])
+                self.layout_info = dict(self.layout_info or {}, slot_placement={
+                    "tile_model_ms_per_plan": [round(before, 2), round(after, 2)], "seconds": round(time.perf_counter() - t0, 3)})
         return Plan(executions, mappings, starts)
 
     def passes_per_step(self, plan: Plan) -> int:

@@ -209,6 +209,7 @@ def plan_partition(ops, n: int, k: int, min_ops: int = 20, full_width: bool = Tr
         close()
         if len(steps) > first_step:
             steps[first_step]["tile_masks"] = list(seg["masks"])   # the tiles of the segment's passes, in order
+            steps[first_step]["tile_needs"] = list(seg["needs"])   # ... and the bits of each that its ops need (the rest is fill)
         seg_info.append({"ops": len(seg["idx"]), "passes": len(seg["masks"]), "tile_masks": list(seg["masks"])})
         if seg["relayout"]:
             steps.append({"local_ops": [], "nonlocal_ops": [(pr, _SWAP) for pr in seg["relayout"]]})
@@ -255,3 +256,58 @@ def plan_partition_best(ops, n: int, k: int, choices=MIN_OPS_CHOICES, threads: i
     out["tried"] = [{"min_ops": j[0], "full_width": j[1], "passes": r["passes"], "relayouts": r["relayouts"], "cost": round(r["cost"], 2)}
                     for j, r in zip(jobs, results)]
     return out
+
+
+def place_slots(executions: list, k: int, seeds=range(1, 5)) -> tuple:
+    """Which index bit every LOCAL SLOT of a planned partition schedule should be, for the DRAM pattern of its tiles.
+
+    A schedule of `plan_partition` is invariant under a permutation of the local index bits above the line bits, applied to
+    everything at once (ops, tiles, the local side of every re-layout, the start layout): a qubit that comes in later takes
+    the slot of the one that left.  What a pass costs depends on WHICH index bits its tile holds (runner/tile_layout.py: a
+    model fitted to measured passes), so the permutation is chosen by annealing the model's total over the tiles' NEEDED
+    bits of all executions (qsim_choose_layout), and then every tile's FILL bits -- free per pass -- are picked greedily
+    under the same model (never the slab bits of the re-layout the pass stores into).  Rewrites the steps of `executions`
+    (lists of steps, chained: execution i + 1 starts in the layout execution i leaves) in place.
+    -> (sigma: old local bit -> new local bit over all n bits touched, model ms before, model ms after)."""
+    from quantum_simulations_amd.runner import tile_layout
+    model = tile_layout.model_for(k)
+    needs = [m for steps in executions for st in steps for m in st.get("tile_needs", [])]
+    if not needs:
+        return None, 0.0, 0.0
+    bits_of = lambda m: [b for b in range(LINE_BITS, k) if (int(m) >> b) & 1]          # noqa: E731
+    before = sum(tile_layout.tile_cost(model, bits_of(m)) for steps in executions for st in steps for m in st.get("tile_masks", []))
+    sigma_k, _c0, _c1 = min((tile_layout.choose_layout([bits_of(m) for m in needs], k, seed=sd) for sd in seeds), key=lambda r: r[2])
+    sigma = {b: int(sigma_k[b]) for b in range(k)}
+
+    def mp(b: int) -> int:
+        return sigma.get(int(b), int(b))
+    after = 0.0
+    for steps in executions:
+        for i, st in enumerate(steps):
+            st["local_ops"] = [([mp(q) for q in qs], U) for qs, U in st["local_ops"]]
+            st["nonlocal_ops"] = [([mp(q) for q in qs], U) for qs, U in st["nonlocal_ops"]]
+        # tiles: the needed bits move with their slots, the fill is chosen anew
+        seg_first = [i for i, st in enumerate(steps) if "tile_needs" in st]
+        for j, i in enumerate(seg_first):
+            st = steps[i]
+            end = seg_first[j + 1] if j + 1 < len(seg_first) else len(steps)
+            slab = 0                          # local bits of the re-layout that closes this segment (already mapped)
+            for later in steps[i:end]:
+                for qs, U in later["nonlocal_ops"]:
+                    if len(qs) == 2 and U.shape == (4, 4) and np.array_equal(U, _SWAP) and (qs[0] < k) != (qs[1] < k):
+                        slab |= 1 << min(qs)
+            new_masks, new_needs = [], []
+            for pi, (mask, need) in enumerate(zip(st["tile_masks"], st["tile_needs"])):
+                want = bin(int(mask)).count("1")
+                tile = [mp(b) for b in bits_of(need)]
+                forbid = slab if pi == len(st["tile_masks"]) - 1 else 0
+                while len(tile) < want:
+                    cands = [b for b in range(LINE_BITS, k) if b not in tile and not (forbid >> b) & 1]
+                    if not cands:
+                        cands = [b for b in range(LINE_BITS, k) if b not in tile]
+                    tile.append(min(cands, key=lambda b: (tile_layout.tile_cost(model, tile + [b]), b)))
+                after += tile_layout.tile_cost(model, tile)
+                new_masks.append(sum(1 << b for b in tile))
+                new_needs.append(sum(1 << mp(b) for b in bits_of(need)))
+            st["tile_masks"], st["tile_needs"] = new_masks, new_needs
+    return sigma, before, after
