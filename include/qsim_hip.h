@@ -71,6 +71,9 @@ int qsim_download(qsim_chunk* c, double* re_im, uint64_t offset_amps, uint64_t c
 int qsim_download_c64(qsim_chunk* c, float* re_im, uint64_t offset_amps, uint64_t count);
 int qsim_upload_c64(qsim_chunk* c, const float* re_im, uint64_t offset_amps, uint64_t count);
 int qsim_copy(qsim_chunk* dst, const qsim_chunk* src);    /* device-to-device, same k  */
+/* measurement aid (bench.py `stream_ceiling`): the same copy through a named path -- 0: qsim_copy's own choice, 1: the
+ * non-temporal kernel, 2: the plain (cached) kernel, 3: hipMemcpyAsync device-to-device (the runtime's blit kernel) */
+int qsim_copy_variant(qsim_chunk* dst, const qsim_chunk* src, int variant);
 
 /* ---- local butterflies (cpu_scalar.apply_1q / apply_2q) --------------------------- */
 int qsim_apply_1q(qsim_chunk* c, int qubit, const double U[8]);

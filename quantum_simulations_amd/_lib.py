@@ -52,6 +52,7 @@ SIGNATURES = {
     "qsim_download_c64": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
     "qsim_upload_c64": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
     "qsim_copy": (C.c_int, [_P, _P]),
+    "qsim_copy_variant": (C.c_int, [_P, _P, C.c_int]),
     "qsim_apply_1q": (C.c_int, [_P, C.c_int, _P]),
     "qsim_apply_2q": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "qsim_apply_fused_k": (C.c_int, [_P, C.c_int, _P, _P]),

@@ -294,6 +294,27 @@ int qsim_copy(qsim_chunk* dst, const qsim_chunk* src) {
   return QSIM_OK;
 }
 
+// The streaming candidates behind bench.py's `stream_ceiling`: variant 0 = qsim_copy's own choice, 1 = the non-temporal
+// copy kernel whatever the size, 2 = the plain (cached) copy kernel, 3 = hipMemcpyAsync device to device (the runtime's
+// blit kernel).  Measurement aid: same arguments and stream semantics as qsim_copy.
+int qsim_copy_variant(qsim_chunk* dst, const qsim_chunk* src, int variant) {
+  if (variant == 0) return qsim_copy(dst, src);
+  int rc = check_chunk(dst, "qsim_copy_variant");
+  if (rc || (rc = check_chunk(src, "qsim_copy_variant"))) return rc;
+  if (dst->k != src->k) return fail(QSIM_ERR_INVALID, "qsim_copy_variant: sizes differ");
+  if (dst->amp == src->amp) return fail(QSIM_ERR_INVALID, "qsim_copy_variant: source and destination are the same buffer");
+  HIP_TRY(hipSetDevice(dst->device));
+  constexpr int kItems = 2;
+  u64 blocks = (amps(dst) + (u64)kBlock * kItems - 1) / ((u64)kBlock * kItems);
+  blocks = (blocks + 7) & ~7ull;
+  if (variant == 1) hipLaunchKernelGGL((k_copy<true, kItems>), grid_for(blocks), dim3(kBlock), 0, dst->stream, dst->amp, src->amp, amps(dst));
+  else if (variant == 2) hipLaunchKernelGGL((k_copy<false, kItems>), grid_for(blocks), dim3(kBlock), 0, dst->stream, dst->amp, src->amp, amps(dst));
+  else if (variant == 3) HIP_TRY(hipMemcpyAsync(dst->amp, src->amp, sizeof(double2) << dst->k, hipMemcpyDeviceToDevice, dst->stream));
+  else return fail(QSIM_ERR_INVALID, "qsim_copy_variant: variant %d", variant);
+  HIP_TRY(hipGetLastError());
+  return QSIM_OK;
+}
+
 int qsim_apply_1q(qsim_chunk* c, int qubit, const double U[8]) {
   int rc = check_chunk(c, "qsim_apply_1q");
   if (rc || (rc = check_local_qubit(c, qubit))) return rc;

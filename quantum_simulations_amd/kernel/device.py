@@ -127,8 +127,12 @@ class DeviceChunk:
         a = np.ascontiguousarray(arr, dtype=np.complex64)
         _lib.check(_lib.load().qsim_upload_c64(self._h, a.ctypes.data_as(C.c_void_p), int(offset), int(a.size)))
 
-    def copy_from(self, other: "DeviceChunk") -> None:
-        _lib.check(_lib.load().qsim_copy(self._h, other._h))
+    def copy_from(self, other: "DeviceChunk", variant: int = 0) -> None:
+        """variant (measurement aid, qsim_copy_variant): 0 the library's choice, 1 non-temporal kernel, 2 plain kernel, 3 hipMemcpyAsync"""
+        if variant:
+            _lib.check(_lib.load().qsim_copy_variant(self._h, other._h, int(variant)))
+        else:
+            _lib.check(_lib.load().qsim_copy(self._h, other._h))
 
     # ---- gates --------------------------------------------------------------------
     def apply_1q(self, qubit: int, U: np.ndarray) -> None:

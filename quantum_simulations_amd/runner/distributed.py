@@ -785,14 +785,16 @@ class DistributedEngine:
                             "search_seconds": round(time.perf_counter() - t0, 3)}
         return cands[best]
 
-    def plan(self, circuit_dict: dict, repeats: int = 1) -> Plan:
+    def plan(self, circuit_dict: dict, repeats: int = 1, effort: str | None = None) -> Plan:
         """Step lists for `repeats` successive executions from the engine's current layout.  COLLECTIVE when it is the first
         plan of a freshly initialised state and the engine searches the initial layout (every rank must call it: rank 0's
         choice is broadcast); host-only otherwise."""
         cd = validate_circuit_dict(circuit_dict)
         if cd["number_of_qubits"] != self.n:
             raise ValueError(f"circuit has {cd['number_of_qubits']} qubits, engine has {self.n}")
-        self._plan_effort_high = repeats >= self.LAYOUT_MIN_REPEATS or self.layout == "search"
+        # effort: "high" = the full search of start layouts and thin-pass thresholds (seconds of host time: worth it for a
+        # plan that runs many times), "low" = two start layouts, two thresholds; None: by `repeats`
+        self._plan_effort_high = (effort == "high") if effort else (repeats >= self.LAYOUT_MIN_REPEATS or self.layout == "search")
         was_fresh = self._fresh and self.layout != "identity"
         if self._fresh:
             # (once per initialised state: a second plan made before the first one runs keeps this layout, so both stay valid)

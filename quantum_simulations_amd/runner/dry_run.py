@@ -63,7 +63,8 @@ def run_world(world: int, rank: int, k: int, emit=print) -> int:
         # exact op lists, host only -- so the line carries the compute side of the schedule next to its transfers)
         eng = DistributedEngine(n, world, rank, backend=PlanningBackend(k), staging=staging)
         eng.init_zero_state()
-        plan = eng.plan(cd, repeats=repeats)
+        # (the bench plans its circuit for warmup + steps executions: the full planning effort; two of them are run here)
+        plan = eng.plan(cd, repeats=repeats, effort="high" if repeats > 1 else None)
         passes = []
         for _ in range(repeats):
             eng.execute(plan)

@@ -277,6 +277,38 @@ class SingleGpuEngine:
         return {"GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4), "ms": round(ms, 4),
                 "bytes": 32 * (1 << self.n), "kernel": "k_copy (read + write, non-temporal above 256 MiB)"}
 
+    def stream_ceiling(self, reps: int = 5) -> dict:
+        """What this device streams at the state's size in THIS run: the best of the copy kernel (non-temporal and plain),
+        the runtime's device-to-device copy, and an in-place read-modify-write of every amplitude (H on a middle index
+        bit: one 32-B round trip per amplitude, the access pattern of the gate kernels themselves).  All move 32 B per
+        amplitude.  bench.py reports the fused pass against the best of them (`frac_of_achievable`): unlike the copy
+        kernel alone (r04: 0.71 of peak while the in-place H reached 0.77 in the same run) the maximum IS a ceiling of
+        what was seen to stream on this box."""
+        other = DeviceChunk.empty(self.n, self.state.device)
+        nbytes = 32.0 * (1 << self.n)
+        H = gate_table.H()
+
+        def timed(fn) -> float:
+            fn()
+            other.sync()
+            ts = []
+            for _ in range(reps):
+                other.time_begin()
+                fn()
+                ts.append(other.time_end())
+            return float(np.median(ts))
+        other.copy_from(self.state)
+        rows = {"copy_nontemporal": timed(lambda: other.copy_from(self.state, 1)),
+                "copy_plain": timed(lambda: other.copy_from(self.state, 2)),
+                "copy_hipMemcpyAsync": timed(lambda: other.copy_from(self.state, 3)),
+                "inplace_rmw_H_bit12": timed(lambda: other.apply_1q(min(12, self.n - 1), H)),
+                "inplace_rmw_H_bit5": timed(lambda: other.apply_1q(min(5, self.n - 1), H))}
+        other.close()
+        gbps = {name: round(nbytes / (ms * 1e-3) / 1e9, 1) for name, ms in rows.items()}
+        best = max(gbps, key=gbps.get)
+        return {"GBps": gbps[best], "best": best, "frac_of_8TBps": round(gbps[best] / 8000.0, 4), "candidates_GBps": gbps,
+                "bytes": int(nbytes), "note": "each candidate moves 32 B per amplitude of a buffer of the state's size; median of %d" % reps}
+
     def prefix_parity(self, circuit_dict: dict, n_gates: int, expected: np.ndarray) -> float:
         """max |amp - expected| after the first n_gates gates from |0..0> (checker hook for bench.py's CPU leg; runs
         outside every timed region) -- through the SAME path as the timed steps: planned by `plan` (layout search and named

@@ -137,13 +137,18 @@ def plan_partition(ops, n: int, k: int, min_ops: int = 20, full_width: bool = Tr
         use = next_target_use()
         waiting = any(use[q] != never for q in range(n) if cur[q] >= k)      # an op somewhere waits for a rank bit
         fresh_segment = len(segments) > 1 and not segments[-1]["masks"]      # (a re-layout right behind a re-layout buys nothing)
-        if members and (len(members) >= min_ops or not waiting or fresh_segment):
+        last_need = segments[-1]["needs"][-1] if segments[-1]["needs"] else 0
+        # The LAST re-layout can come as early as p local qubits are finished (never a target again): they leave, every
+        # global qubit comes in, and nothing will ever wait for a rank bit again -- the ops that wait now join the passes
+        # from here on instead of filling thin ones at the end (GHZ+QFT: 8 -> 6 passes at 33 qubits).
+        finished = [q for q in range(n) if LINE_BITS <= cur[q] < k and use[q] == never and not (last_need >> int(cur[q])) & 1]
+        final_now = waiting and not fresh_segment and len(finished) >= p and segments[-1]["masks"]
+        if members and not final_now and (len(members) >= min_ops or not waiting or fresh_segment):
             commit(mask, need, members)
             continue
         # A thin pass: is there a better global set?  Farthest next use as a target goes out.  The slab bits of a fused
         # re-layout must not be tile bits of the pass that stores the slabs (the segment's last): qubits that pass needs as
         # tile bits are no candidates (its fill bits are re-chosen below); qubits on the line bits never are.
-        last_need = segments[-1]["needs"][-1] if segments[-1]["needs"] else 0
         glob = [q for q in range(n) if cur[q] >= k]
         local = [q for q in range(n) if LINE_BITS <= cur[q] < k]
         if sum(1 for q in local if not (last_need >> int(cur[q])) & 1) >= p:
@@ -258,7 +263,7 @@ def plan_partition_best(ops, n: int, k: int, choices=MIN_OPS_CHOICES, threads: i
     return out
 
 
-def place_slots(executions: list, k: int, seeds=range(1, 5)) -> tuple:
+def place_slots(executions: list, k: int, seeds=(1, 2), fit_executions: int = 6) -> tuple:
     """Which index bit every LOCAL SLOT of a planned partition schedule should be, for the DRAM pattern of its tiles.
 
     A schedule of `plan_partition` is invariant under a permutation of the local index bits above the line bits, applied to
@@ -276,7 +281,9 @@ def place_slots(executions: list, k: int, seeds=range(1, 5)) -> tuple:
         return None, 0.0, 0.0
     bits_of = lambda m: [b for b in range(LINE_BITS, k) if (int(m) >> b) & 1]          # noqa: E731
     before = sum(tile_layout.tile_cost(model, bits_of(m)) for steps in executions for st in steps for m in st.get("tile_masks", []))
-    sigma_k, _c0, _c1 = min((tile_layout.choose_layout([bits_of(m) for m in needs], k, seed=sd) for sd in seeds), key=lambda r: r[2])
+    # (the annealing takes time in proportion to the tiles: a long chain of executions is fitted on its first few)
+    fit = [m for steps in executions[:max(1, fit_executions)] for st in steps for m in st.get("tile_needs", [])]
+    sigma_k, _c0, _c1 = min((tile_layout.choose_layout([bits_of(m) for m in fit], k, seed=sd) for sd in seeds), key=lambda r: r[2])
     sigma = {b: int(sigma_k[b]) for b in range(k)}
 
     def mp(b: int) -> int:

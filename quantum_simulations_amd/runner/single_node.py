@@ -62,7 +62,7 @@ def build_steps(cd: dict, k: int, use_fusion: bool, use_staging: bool, staging_m
     return steps, None
 
 
-def _plan_fingerprint(steps, k: int, use_fusion: bool, use_staging: bool, staging_method: str) -> dict:
+def _plan_fingerprint(steps, k: int, use_fusion: bool, use_staging: bool, staging_method: str, n_qubits: int | None = None) -> dict:
     """What `done_steps` of a checkpoint refers to: the step list depends on the planner flags, so a
     resumed run must have planned the same steps (qubit lists of every step, hashed)."""
     import hashlib
@@ -71,9 +71,12 @@ def _plan_fingerprint(steps, k: int, use_fusion: bool, use_staging: bool, stagin
         for part in ("local_ops", "nonlocal_ops"):
             h.update(repr([list(map(int, qs)) for qs, _ in st[part]]).encode())
             h.update(b"|")
-    return {"k": k, "use_fusion": bool(use_fusion), "use_staging": bool(use_staging),
-            "staging_method": staging_method if use_staging else None, "n_steps": len(steps),
-            "steps_sha256": h.hexdigest()}
+    out = {"k": k, "use_fusion": bool(use_fusion), "use_staging": bool(use_staging),
+           "staging_method": staging_method if use_staging else None, "n_steps": len(steps),
+           "steps_sha256": h.hexdigest()}
+    if n_qubits is not None:
+        out["n_qubits"] = int(n_qubits)       # (compared with the committed buffer's manifest on a resume without plan.json)
+    return out
 
 
 def _check_plan_sidecar(work: Path, first_step: int, fingerprint: dict, committed_manifest: dict | None = None) -> None:
@@ -113,6 +116,9 @@ def _check_plan_sidecar(work: Path, first_step: int, fingerprint: dict, committe
                                      "lists differ; refusing to resume")
         plan_path.write_text(json.dumps(fingerprint))
         return
+    if "n_qubits" not in saved or "n_qubits" not in fingerprint:    # (a sidecar written before the qubit count was recorded)
+        saved = {key: v for key, v in saved.items() if key != "n_qubits"}
+        fingerprint = {key: v for key, v in fingerprint.items() if key != "n_qubits"}
     if saved != fingerprint:
         raise ValueError(f"checkpoint in {work} was written under a different plan (chunk_size / use_fusion / "
                          f"use_staging / staging_method): saved {saved}, now {fingerprint}; refusing to resume")
@@ -148,13 +154,13 @@ def run(circuit_dict: dict, work_dir: str | Path | None = None, chunk_size: int 
         from quantum_simulations_amd.wal import WAL
         log = WAL(work / "wal.json", circuit_dict=cd)   # raises on a different circuit
         first_step = log.done_steps
-        fingerprint = _plan_fingerprint(steps, k, use_fusion, use_staging, staging_method)
+        fingerprint = _plan_fingerprint(steps, k, use_fusion, use_staging, staging_method, n_qubits=n)
         committed_manifest = None
         if first_step > 0:
             try:
                 from quantum_simulations_amd.storage.block_store import read_manifest
                 committed_manifest = read_manifest(work / f"state_{log.committed_buf}")
-            except (OSError, ValueError):
+            except (OSError, ValueError, KeyError):
                 committed_manifest = None           # (load_to_device below reports a missing / broken buffer)
         _check_plan_sidecar(work, first_step, fingerprint, committed_manifest)
         first_step = min(first_step, len(steps))

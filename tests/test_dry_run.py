@@ -67,7 +67,23 @@ def test_schedule_is_symmetric_at_full_size(world):
         assert max(spread) <= 4, spread
         info = d["layout_search_rank0"]
         assert info is not None and info["chosen"]["cost_max_over_ranks"] <= info["identity"]["cost_max_over_ranks"]
-        assert info["chosen"]["passes_this_rank"] == d["per_rank"][0]["hbm_passes_per_execution"][0]     # what was priced is what ran
+        assert "search_seconds" in info                      # (the host time of the search is in the record)
+        # what was priced is what ran: the start layouts are priced with one thin-pass threshold, the plan that runs is the
+        # best over several (staging method "tiles"), so it may need a pass less, never more than one more
+        ran = d["per_rank"][0]["hbm_passes_per_execution"][0]
+        assert ran <= info["chosen"]["passes_this_rank"] + 1, (ran, info["chosen"])
+        if d["dry_run"].startswith("bench") or "staged" in d["dry_run"].split(",")[-1] and "unstaged" not in d["dry_run"]:
+            # stage boundaries and tile passes planned together: EVERY rank runs the planned passes (the planner names its
+            # tiles to the library), so the ranks agree exactly
+            assert max(spread) == 0, spread
+    # passes per execution of a 30-local-qubit shard (r04: 33 / 32 at 33 qubits on 8 ranks, 28 at 32 on
+    # 4; Clifford+T staged 21) with no more re-layouts and no more bytes than before
+    bench = next(d for d in docs if d["dry_run"].startswith("bench"))
+    cliff = next(d for d in docs if d["dry_run"] == "config 4: Clifford+T depth 60, staged")
+    worst = max(max(r["hbm_passes_per_execution"]) for r in bench["per_rank"])
+    assert worst <= (26 if world == 8 else 23), worst
+    assert bench["per_rank"][0]["exchanges"] <= 8 and bench["per_rank"][0]["bytes_sent"] <= 8 * (shard - (shard >> (world.bit_length() - 1)))
+    assert max(max(r["hbm_passes_per_execution"]) for r in cliff["per_rank"]) <= 18 and cliff["per_rank"][0]["exchanges"] <= 3
     # GHZ needs exactly one re-layout of all global qubits: (1 - 2^-p) of a shard per rank
     ghz = next(d for d in docs if d["dry_run"] == "config 5: GHZ")
     p = world.bit_length() - 1

@@ -181,3 +181,21 @@ def test_resume_without_sidecar_checks_the_manifest_chunk_size(tmp_path):
     (tmp_path / "plan.json").unlink()
     with pytest.raises(ValueError, match="staged"):
         _check_plan_sidecar(tmp_path, 3, dict(fp, use_staging=True, staging_method="heuristic"), {"chunk_size": 16})
+    # the fingerprint of a real run carries the qubit count (so that half of the check is live) ...
+    from quantum_simulations_amd.runner.single_node import _plan_fingerprint
+    fp_n = _plan_fingerprint([], 4, False, False, "heuristic", n_qubits=6)
+    assert fp_n["n_qubits"] == 6
+    with pytest.raises(ValueError, match="n_qubits = 7"):
+        _check_plan_sidecar(tmp_path, 0 + 3, dict(fp, n_qubits=6), {"chunk_size": 16, "n_qubits": 7})
+    # ... a sidecar written before the count was recorded still matches the same plan ...
+    (tmp_path / "plan.json").write_text(__import__("json").dumps(fp))
+    _check_plan_sidecar(tmp_path, 3, dict(fp, n_qubits=6), None)
+    # ... and a manifest that lacks a key makes the resume fall through to the loader's own error, not a KeyError here
+    import json as _json
+
+    from quantum_simulations_amd.storage import block_store
+    bad = tmp_path / "state_a"
+    bad.mkdir()
+    (bad / "manifest.json").write_text(_json.dumps({"n_qubits": 6}))
+    with pytest.raises((KeyError, ValueError)):
+        block_store.read_manifest(bad)
