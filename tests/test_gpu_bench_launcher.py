@@ -62,5 +62,16 @@ def test_single_gpu_line_carries_the_contract_fields():
         blocks = sweep["dense_blocks"][f"k={k}"]
         assert len(blocks["qubit_sets"]) == 4 and all(f > 0 for f in blocks["frac_of_8TBps"]) and "mfma" in blocks["kernel"]
     assert abs(sweep["norm2_after"] - 1.0) < 1e-10
+    # what ONE call of the drop-in entry points costs, next to the steady-state value; item 7: the
+    # streaming ceiling seen in this run and the layout facts at the top level; ADVICE r04: the timed plan itself is checked
+    api = d["api_path"]
+    for entry in ("single_node.run", "Driver.run_circuit"):
+        assert api[entry]["seconds"] > 0 and api[entry]["gate_apps_per_s"] > 0 and api[entry]["fingerprint_abs_diff_vs_engine"] < 1e-10
+    assert d["first_execution_ms"] > 0 and d["plan_seconds"] >= 0 and d["layout"] in ("identity", "searched")
+    assert "qubit_layout_seconds" in d and "value_is" in d["config"]
+    sc = d["stream_ceiling"]
+    assert sc["GBps"] == max(sc["candidates_GBps"].values()) and sc["GBps"] >= d["copy_ceiling"]["GBps"] * 0.98
+    assert abs(d["roofline"]["frac_of_achievable"] - d["roofline"]["achieved"] / sc["GBps"]) < 1e-3
+    assert d["timed_plan_check"]["fingerprint_abs_diff_vs_identity_layout_plan"] < 1e-10
     bad = subprocess.run(cmd, cwd=ROOT, env=dict(env, QSIM_PLAN_LOOKAHEAD="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode == 2 and "refusing" in bad.stdout
