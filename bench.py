@@ -252,6 +252,8 @@ def api_path_record(circuit: dict, device: int, engine, invalid: list) -> dict:
     engine.layout_mode = saved_mode
     want = engine.state.fingerprint(n, 0, None, seed)
     rec = {}
+    from quantum_simulations_amd import _lib
+    _lib.check(_lib.load().qsim_plan_cache_clear())      # COLD: the library plans the op list inside the timed call
     t0 = time.perf_counter()
     buf = single_node.run(circuit, None, chunk_size=1 << n, use_fusion=True, device=device)
     buf.state.sync()
@@ -263,6 +265,7 @@ def api_path_record(circuit: dict, device: int, engine, invalid: list) -> dict:
     buf.close()
     if not diff < PARITY_TOL:
         invalid.append(f"api_path single_node.run: fingerprint differs from the engine's by {diff:.3e}")
+    _lib.check(_lib.load().qsim_plan_cache_clear())
     t0 = time.perf_counter()
     with Driver(device=device) as drv:
         res = drv.run_circuit(circuit)

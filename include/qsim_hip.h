@@ -78,12 +78,14 @@ int qsim_copy_variant(qsim_chunk* dst, const qsim_chunk* src, int variant);
 /* ---- local butterflies (cpu_scalar.apply_1q / apply_2q) --------------------------- */
 int qsim_apply_1q(qsim_chunk* c, int qubit, const double U[8]);
 int qsim_apply_2q(qsim_chunk* c, int qa, int qb, const double U[32]);
-/* Dense k-qubit block (1 <= k <= 4): v3's fused block as a genuine 2^k x 2^k contraction -- `_apply_combined_matrix`,
+/* Dense k-qubit block (1 <= k <= 6): v3's fused block as a genuine 2^k x 2^k contraction -- `_apply_combined_matrix`,
  * v3_hisvsim_spark/src/parallel_gate_applicator.py:315-385.  M row-major 2^k x 2^k (re, im interleaved), M[out][in], pattern
  * bit i <-> qubits[i] (little-endian over the list, :169-204):  new[idx | out] = sum_in M[out][in] old[idx | in].  A block that
  * is a tensor product of 1q gates is cheaper as butterflies of a fused pass (qsim_apply_ops); this entry is for matrices
- * that are dense to begin with: k = 3, 4 run on the matrix cores (v_mfma_f64_16x16x4_f64 over 16 blocks at a time, in
- * place; 0.67-0.74 of the HBM peak at 30 qubits), k = 1, 2 on the pair kernels. */
+ * that are dense to begin with: k = 3 .. 6 run on the matrix cores (v_mfma_f64_16x16x4_f64 over 16 blocks at a time, in
+ * place; the real image of the matrix in registers for k = 3, 4 and in LDS for k = 5, 6: 8 * 2^k flop per amplitude over
+ * the same 32 bytes, so k <= 5 is bound by HBM and k = 6 by the matrix cores), k = 1, 2 on the pair kernels; chunks of fewer
+ * than 2^(k+4) amplitudes take a one-workgroup-per-block form. */
 int qsim_apply_fused_k(qsim_chunk* c, int k, const int32_t* qubits, const double* M);
 /* A pass of n_ops gates in order (single_node._process_local_chunk, :208-216).
  * nq[i] in {1,2}; qubits[2*i], qubits[2*i+1]; mats + 32*i holds U (8 or 32 doubles). */
@@ -96,6 +98,7 @@ int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* q
 int qsim_apply_ops_unfused(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* qubits,
                            const double* mats);
 int qsim_last_pass_count(const qsim_chunk* c);
+int qsim_plan_cache_clear(void);   /* forget the cached pass images of earlier op lists: the next qsim_apply_ops* call plans anew */
 /* qsim_apply_ops with the high tile bits of the first n_tiles fused passes named by the caller (bit b of tile_masks[p]: index
  * bit b is a tile bit of pass p) instead of searched for: a host that planned the list once (qsim_plan_ops: every pass image
  * carries its tile bits) and then moved its qubits to other index bits -- a layout chosen for the DRAM pattern of the tiles,

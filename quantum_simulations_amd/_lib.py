@@ -66,6 +66,7 @@ SIGNATURES = {
     "qsim_plan_peek_pass": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_uint64), C.POINTER(C.c_int32), _P]),
     "qsim_last_pass_count": (C.c_int, [_P]),
+    "qsim_plan_cache_clear": (C.c_int, []),
     "qsim_apply_ops_io": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.POINTER(C.c_int)]),
     "qsim_apply_ops_io_part": (C.c_int, [_P, C.c_int]),
     "qsim_apply_ops_io_load": (C.c_int, [_P, C.c_int]),

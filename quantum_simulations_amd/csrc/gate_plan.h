@@ -55,6 +55,7 @@ struct Tuning {
   int tile_sink_swaps = 1;   // X / CNOT that nothing later in their group touches: swap LDS addresses at write-back (OPC_ASWAP1)
   int tile_group_search = 1; // register groups: try every triple of pending target bits, not only first come
   int tile_had = QSIM_TILE_HAD_DEFAULT;          // uncontrolled c [[1,1],[1,-1]] as add/sub butterflies + one scale per pass (OPC_HAD1 / OPC_SCALE)
+  int dense_form = 1;        // (probe build) qsim_apply_fused_k, k = 3, 4: 1 = k_dense_mfma2 (round 5: whole amplitudes per lane), 0 = the round-4 kernels chosen by dense_mfma; QSIM_DENSE_FORM
   int dense_mfma = 3;        // qsim_apply_fused_k: bit 0: k = 3, bit 1: k = 4 on the matrix cores (k_dense_mfma; else the vector-ALU k_dense; probe knob QSIM_DENSE_MFMA)
   int debug_skip_gates = 0;  // probe build only: QSIM_DEBUG_SKIP_GATES=1: tile passes move data but apply nothing (WRONG results)
   int tile_order = -1;       // probe build only: QSIM_TILE_ORDER=0/1/2 forces the tile order of k_tile
@@ -84,6 +85,7 @@ struct Tuning {
     if (const char* e = getenv("QSIM_PLAN_FORCE_LOW")) plan_force_low = std::max(0, std::min(6, atoi(e)));
     if (const char* e = getenv("QSIM_PLAN_SCAN_WINDOW")) plan_scan_window = std::max(1, atoi(e));
     if (const char* e = getenv("QSIM_DENSE_MFMA")) dense_mfma = atoi(e);
+    if (const char* e = getenv("QSIM_DENSE_FORM")) dense_form = atoi(e);
     if (const char* e = getenv("QSIM_PLAN_ANCHOR")) plan_anchor = std::max(0, std::min(7, atoi(e)));
     if (const char* e = getenv("QSIM_TILE_MUX")) tile_mux = atoi(e);
     if (const char* e = getenv("QSIM_TILE_COMMUTE_FUSE")) tile_commute_fuse = atoi(e);

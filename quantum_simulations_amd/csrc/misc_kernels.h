@@ -375,6 +375,8 @@ __global__ __launch_bounds__(kBlock) void k_dense(const DenseArgs a) {
 // 0.68-0.73 of the HBM peak against 0.43 for the vector-ALU form (k_dense<4>: 256 complex multiply-adds per work item at 128+
 // VGPRs) -- the one place of this path where the work IS a matrix product (north star: "MFMA only for fused
 // multi-qubit dense blocks where it is a real 2^k x 2^k contraction").
+typedef double qs_double4_t __attribute__((ext_vector_type(4)));
+#ifdef QSIM_PROBES          // (the round-4 form: kept in the probe build as the A/B partner of k_dense_mfma2 below)
 struct DenseMfmaArgs {
   double* amp;              // the chunk as reals
   const double2* mat;       // the caller's 2^K x 2^K complex matrix, row-major M[out][in] (its real image is formed in registers)
@@ -383,7 +385,6 @@ struct DenseMfmaArgs {
   int bit[4];               // pattern bit i <-> index bit bit[i] (the caller's qubit order)
 };
 constexpr int kDenseMfmaColBlocksPerWave = 4;
-typedef double qs_double4_t __attribute__((ext_vector_type(4)));
 template <int K, bool NT>
 __global__ __launch_bounds__(kBlock) void k_dense_mfma(const DenseMfmaArgs a) {
   static_assert(K == 3 || K == 4, "16-row MFMA tiles: 16 or 32 reals per block");
@@ -439,10 +440,153 @@ __global__ __launch_bounds__(kBlock) void k_dense_mfma(const DenseMfmaArgs a) {
   }
 }
 
+#endif  // QSIM_PROBES
+
+// Dense K-qubit blocks, K = 3 .. 6, on the matrix cores -- second form (round 5).  Same product as k_dense_mfma (a real
+// 2^(K+1) x 2^(K+1) matrix times the reals of 16 blocks per wave and step, v_mfma_f64_16x16x4_f64), with two changes:
+//   * the ROWS are ordered so that a lane owns WHOLE amplitudes: row r = 4 s + g with s = 2 mu + c -- g = the two LOWEST
+//     pattern bits (the block's two lowest index bits), c = component (0 real, 1 imaginary), mu = the upper K - 2 pattern
+//     bits.  Lane (j = l & 15, g = l >> 4) then holds the 2^(K-2) amplitudes { pattern 4 mu + g } of column j as double2 and
+//     gets them back at the same places (D element i of row tile t is row 16 t + 4 i + g: s' = 4 t + i): 16-byte accesses,
+//     in place, no LDS for the state, no shuffles.  With the block's lowest bits inside a 128-byte line the four g lanes of
+//     a column cover 64 contiguous bytes and two neighbouring columns the rest of the line (r04's form touched every line
+//     with four 32-byte pieces: 0.40 of peak on blocks over index bits 0-2);
+//   * K = 5 and 6: the matrix image no longer fits registers (16 x 2^(K-1) / 64 ... = 64 / 256 doubles per lane), so every
+//     workgroup keeps it in LDS in A-OPERAND layout -- tab[(t S + s) 64 + lane] = Mr[16 t + (lane & 15)][4 s + (lane >> 4)],
+//     32 / 128 KiB -- and each MFMA takes its A operand with one conflict-free ds_read_b64.  K = 6 is the first kernel of
+//     this path that is NOT bound by HBM: 512 flop per amplitude = 7.0 ms of the 78.6 Tflop/s at 30 qubits against 4.3 ms
+//     of HBM at peak (K = 5: 3.5 ms against 4.3: HBM still).
+// Mr[(mu_o, c_o, g_o)][(mu_i, c_i, g_i)] = Re M[p_o][p_i] if c_o == c_i, Im if (c_o, c_i) = (1, 0), -Im if (0, 1), with
+// p = 4 mu + g in SORTED block-bit order; `to_caller[i]` = the caller's pattern bit of the i-th lowest block bit.
+struct DenseMfma2Args {
+  double2* amp;
+  const double2* mat;       // the caller's 2^K x 2^K complex matrix, row-major M[out][in]
+  u64 col_blocks;           // groups of 16 columns: 2^(k - K - 4)
+  int pos[6];               // the block's index bits, ascending
+  int to_caller[6];         // pattern bit i (sorted order) -> bit of the caller's pattern
+};
+template <int K>
+__device__ __forceinline__ double dense_mr_entry(const DenseMfma2Args& a, int t, int s, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+  const int so = 4 * t + (j >> 2), go = j & 3;
+  const int po = 4 * (so >> 1) + go, co = so & 1, pi = 4 * (s >> 1) + g, ci = s & 1;
+  int ro = 0, ri = 0;
+#pragma unroll
+  for (int i = 0; i < K; ++i) { ro |= ((po >> i) & 1) << a.to_caller[i]; ri |= ((pi >> i) & 1) << a.to_caller[i]; }
+  const double2 z = a.mat[ro * (1 << K) + ri];
+  return co == ci ? z.x : (co ? z.y : -z.y);
+}
+template <int K, bool NT, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_dense_mfma2(const DenseMfma2Args a) {
+  static_assert(K >= 3 && K <= 6, "dense blocks of 3 .. 6 qubits");
+  constexpr int TT = 1 << (K - 3);          // 16-row output tiles
+  constexpr int S = 1 << (K - 1);           // k-steps of 4 rows
+  constexpr int MU = 1 << (K - 2);          // amplitudes per lane and column
+  constexpr bool IN_LDS = K >= 5;
+  __shared__ double tab[IN_LDS ? TT * S * 64 : 1];
+  const int l = threadIdx.x & 63, j = l & 15, g = l >> 4;
+  double A[IN_LDS ? 1 : TT][IN_LDS ? 1 : S];
+  if constexpr (IN_LDS) {
+    for (int idx = threadIdx.x; idx < TT * S * 64; idx += THREADS) tab[idx] = dense_mr_entry<K>(a, idx / (S * 64), (idx >> 6) % S, idx & 63);
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int s = 0; s < S; ++s) A[t][s] = dense_mr_entry<K>(a, t, s, l);
+  }
+  u64 off[MU];              // (wave-uniform) offsets of the upper pattern bits, in amplitudes
+#pragma unroll
+  for (int m = 0; m < MU; ++m) {
+    u64 o = 0;
+#pragma unroll
+    for (int i = 0; i < K - 2; ++i) o |= (u64)((m >> i) & 1) << a.pos[i + 2];
+    off[m] = o;
+  }
+  const u64 lane_part = ((u64)(g & 1) << a.pos[0]) | ((u64)(g >> 1) << a.pos[1]);
+  const u64 n_waves = (u64)gridDim.x * (THREADS / 64);
+  for (u64 cb = (u64)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6); cb < a.col_blocks; cb += n_waves) {   // (wave-uniform)
+    u64 c = cb * 16 + (u64)j;
+#pragma unroll
+    for (int i = 0; i < K; ++i) { const int p = a.pos[i]; c = ((c >> p) << (p + 1)) | (c & ((1ull << p) - 1)); }
+    double2* const p0 = a.amp + (c | lane_part);
+    double2 x[MU];
+#pragma unroll
+    for (int m = 0; m < MU; ++m) x[m] = ld_amp<NT>(p0 + off[m]);
+    qs_double4_t acc[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) acc[t] = qs_double4_t{0.0, 0.0, 0.0, 0.0};
+    if constexpr (IN_LDS) {
+      // A operands from LDS, one k-step ahead of the MFMAs that use them; the scheduling barrier keeps the compiler from
+      // hoisting all TT x S reads to the top (it did: 256 VGPRs and 368 spilled at K = 6)
+      double cur[TT], nxt[TT];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) cur[t] = tab[(t * S) * 64 + l];
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        if (s + 1 < S) {
+#pragma unroll
+          for (int t = 0; t < TT; ++t) nxt[t] = tab[(t * S + s + 1) * 64 + l];
+        }
+        const double b = (s & 1) ? x[s >> 1].y : x[s >> 1].x;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[t], b, acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TT; ++t) cur[t] = nxt[t];
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const double b = (s & 1) ? x[s >> 1].y : x[s >> 1].x;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[IN_LDS ? 0 : t][IN_LDS ? 0 : s], b, acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) st_amp<NT>(p0 + off[2 * t + h], make_double2(acc[t][2 * h], acc[t][2 * h + 1]));
+  }
+}
+
+template <int K, bool NT, int THREADS>
+static void launch_dense_mfma2(const DenseMfma2Args& d, unsigned grid, hipStream_t stream) {
+  hipLaunchKernelGGL((k_dense_mfma2<K, NT, THREADS>), dim3(grid), dim3(THREADS), 0, stream, d);
+}
+
+// Chunks too small for 16 columns per wave (fewer than 2^(K+4) amplitudes): one 64-thread workgroup per block, the block's
+// 2^K amplitudes through LDS.  Correctness path for tiny chunks (tests, chunked runners with small chunk_size).
+struct DenseSmallArgs {
+  double2* amp;
+  const double2* mat;
+  int k;
+  int pos[6];
+  int bit[6];
+};
+__global__ __launch_bounds__(64) void k_dense_small(const DenseSmallArgs a) {
+  __shared__ double2 x[64];
+  const int N = 1 << a.k;
+  u64 c = blockIdx.x;
+  for (int i = 0; i < a.k; ++i) { const int p = a.pos[i]; c = ((c >> p) << (p + 1)) | (c & ((1ull << p) - 1)); }
+  const int r = threadIdx.x;
+  u64 off = 0;
+  for (int i = 0; i < a.k; ++i) off |= (u64)((r >> i) & 1) << a.bit[i];
+  if (r < N) x[r] = a.amp[c | off];
+  __syncthreads();
+  if (r < N) {
+    double2 acc = cmul(a.mat[r * N], x[0]);
+    for (int col = 1; col < N; ++col) acc = cfma(a.mat[r * N + col], x[col], acc);
+    a.amp[c | off] = acc;
+  }
+}
+
+constexpr int kScratchDoubles = 8192;      // >= kReduceBlocks reduction partials, and a 64 x 64 complex matrix (dense blocks)
+static_assert(kScratchDoubles >= kReduceBlocks, "the scratch holds the reduction partials");
 static int ensure_scratch(qsim_chunk* c) {
   if (!c->scratch) {
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMalloc((void**)&c->scratch, sizeof(double) * kReduceBlocks));
+    HIP_TRY(hipMalloc((void**)&c->scratch, sizeof(double) * kScratchDoubles));
   }
   return QSIM_OK;
 }

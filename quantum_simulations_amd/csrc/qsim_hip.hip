@@ -382,12 +382,15 @@ int qsim_apply_ops(qsim_chunk* c, int n_ops, const int32_t* nq, const int32_t* q
 
 // Dense k-qubit block: new[idx with the block's bits = out] = sum_in M[out][in] old[idx with the block's bits = in], pattern
 // bit i <-> qubits[i] -- v3's `_apply_combined_matrix` (parallel_gate_applicator.py:315-385) for a genuinely dense 2^k x 2^k
-// matrix (its tensor-product blocks are cheaper as butterflies inside a fused pass: qsim_apply_ops).  1 <= k <= 4.
+// matrix (its tensor-product blocks are cheaper as butterflies inside a fused pass: qsim_apply_ops).  1 <= k <= 6.
+// k = 1, 2: the pair kernels.  k >= 3 on chunks of >= 2^(k+4) amplitudes: the matrix cores (misc_kernels.h k_dense_mfma2: 16
+// blocks per wave and step as the columns of v_mfma_f64_16x16x4_f64; the matrix image in registers for k = 3, 4, in LDS for
+// k = 5, 6).  Smaller chunks: one workgroup per block through LDS (k_dense_small).
 int qsim_apply_fused_k(qsim_chunk* c, int k, const int32_t* qubits, const double* M) {
   int rc = check_chunk(c, "qsim_apply_fused_k");
   if (rc) return rc;
   if (!qubits || !M) return fail(QSIM_ERR_INVALID, "qsim_apply_fused_k: null argument");
-  if (k < 1 || k > 4) return fail(QSIM_ERR_INVALID, "qsim_apply_fused_k: 1 <= k <= 4 qubits expected, got %d", k);
+  if (k < 1 || k > 6) return fail(QSIM_ERR_INVALID, "qsim_apply_fused_k: 1 <= k <= 6 qubits expected, got %d", k);
   if (parts_pending(c)) return fail(QSIM_ERR_INVALID, "qsim_apply_fused_k: slab pieces of a split qsim_apply_ops_io call are pending on this chunk");
   for (int i = 0; i < k; ++i) {
     if ((rc = check_local_qubit(c, qubits[i]))) return rc;
@@ -398,48 +401,76 @@ int qsim_apply_fused_k(qsim_chunk* c, int k, const int32_t* qubits, const double
   HIP_TRY(hipSetDevice(c->device));
   if ((rc = ensure_scratch(c))) return rc;
   const int N = 1 << k;
-  static_assert(kReduceBlocks * sizeof(double) >= 16 * 16 * sizeof(double2), "the chunk's scratch holds a 16 x 16 complex matrix");
+  static_assert(kScratchDoubles * sizeof(double) >= 64 * 64 * sizeof(double2), "the chunk's scratch holds a 64 x 64 complex matrix");
   HIP_TRY(hipMemcpyAsync(c->scratch, M, sizeof(double2) * (size_t)N * N, hipMemcpyHostToDevice, c->stream));
-  DenseArgs a;
-  a.amp = c->amp;
-  a.mat = reinterpret_cast<const double2*>(c->scratch);
-  a.count = amps(c) >> k;
-  int sorted[4] = {0, 0, 0, 0};
-  for (int i = 0; i < 4; ++i) { a.bit[i] = i < k ? qubits[i] : 0; sorted[i] = i < k ? qubits[i] : 0; }
+  int sorted[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < k; ++i) sorted[i] = qubits[i];
   std::sort(sorted, sorted + k);
-  for (int i = 0; i < 4; ++i) a.pos[i] = sorted[i];
   const bool nt = c->span_bytes > tuning().mall_bytes && sorted[0] >= kLaneCut;
-  if (c->k >= k + 4 && ((tuning().dense_mfma >> (k - 3)) & 1)) {
-    // the matrix-core form (misc_kernels.h k_dense_mfma): 16 columns per wave and step
-    DenseMfmaArgs d;
-    d.amp = reinterpret_cast<double*>(c->amp);
-    d.mat = a.mat;
-    d.col_blocks = amps(c) >> (k + 4);
-    for (int i = 0; i < 4; ++i) { d.pos[i] = sorted[i]; d.bit[i] = i < k ? qubits[i] : 0; }
-    const u64 waves = (d.col_blocks + kDenseMfmaColBlocksPerWave - 1) / kDenseMfmaColBlocksPerWave;
-    u64 wgs = (waves + kBlock / 64 - 1) / (kBlock / 64);
-    wgs = (wgs + 7) & ~7ull;
+#ifdef QSIM_PROBES
+  if (k <= 4 && tuning().dense_form == 0) {          // the round-4 kernels, kept in the probe build as A/B partners
+    DenseArgs a;
+    a.amp = c->amp;
+    a.mat = reinterpret_cast<const double2*>(c->scratch);
+    a.count = amps(c) >> k;
+    for (int i = 0; i < 4; ++i) { a.bit[i] = i < k ? qubits[i] : 0; a.pos[i] = i < k ? sorted[i] : 0; }
     ProfileScope prof(7, 32.0 * (double)amps(c), c->stream, nt);
-    if (k == 3) {
-      if (nt) hipLaunchKernelGGL((k_dense_mfma<3, true>), grid_for(wgs), dim3(kBlock), 0, c->stream, d);
-      else hipLaunchKernelGGL((k_dense_mfma<3, false>), grid_for(wgs), dim3(kBlock), 0, c->stream, d);
+    if (c->k >= k + 4 && ((tuning().dense_mfma >> (k - 3)) & 1)) {
+      DenseMfmaArgs d;
+      d.amp = reinterpret_cast<double*>(c->amp);
+      d.mat = a.mat;
+      d.col_blocks = amps(c) >> (k + 4);
+      for (int i = 0; i < 4; ++i) { d.pos[i] = a.pos[i]; d.bit[i] = a.bit[i]; }
+      const u64 waves = (d.col_blocks + kDenseMfmaColBlocksPerWave - 1) / kDenseMfmaColBlocksPerWave;
+      u64 wgs = (waves + kBlock / 64 - 1) / (kBlock / 64);
+      wgs = (wgs + 7) & ~7ull;
+      if (k == 3) { if (nt) hipLaunchKernelGGL((k_dense_mfma<3, true>), grid_for(wgs), dim3(kBlock), 0, c->stream, d); else hipLaunchKernelGGL((k_dense_mfma<3, false>), grid_for(wgs), dim3(kBlock), 0, c->stream, d); }
+      else { if (nt) hipLaunchKernelGGL((k_dense_mfma<4, true>), grid_for(wgs), dim3(kBlock), 0, c->stream, d); else hipLaunchKernelGGL((k_dense_mfma<4, false>), grid_for(wgs), dim3(kBlock), 0, c->stream, d); }
     } else {
-      if (nt) hipLaunchKernelGGL((k_dense_mfma<4, true>), grid_for(wgs), dim3(kBlock), 0, c->stream, d);
-      else hipLaunchKernelGGL((k_dense_mfma<4, false>), grid_for(wgs), dim3(kBlock), 0, c->stream, d);
+      u64 blocks = (a.count + kBlock - 1) / kBlock;
+      blocks = (blocks + 7) & ~7ull;
+      if (k == 3) { if (nt) hipLaunchKernelGGL((k_dense<3, true>), grid_for(blocks), dim3(kBlock), 0, c->stream, a); else hipLaunchKernelGGL((k_dense<3, false>), grid_for(blocks), dim3(kBlock), 0, c->stream, a); }
+      else { if (nt) hipLaunchKernelGGL((k_dense<4, true>), grid_for(blocks), dim3(kBlock), 0, c->stream, a); else hipLaunchKernelGGL((k_dense<4, false>), grid_for(blocks), dim3(kBlock), 0, c->stream, a); }
     }
     prof.done(c->stream);
     HIP_TRY(hipGetLastError());
     return QSIM_OK;
   }
-  u64 blocks = (a.count + kBlock - 1) / kBlock;
-  blocks = (blocks + 7) & ~7ull;                     // whole octets: logical_block<true> deals blocks over the 8 XCDs
+#endif
   ProfileScope prof(7, 32.0 * (double)amps(c), c->stream, nt);
-  if (k == 3) {
-    if (nt) hipLaunchKernelGGL((k_dense<3, true>), grid_for(blocks), dim3(kBlock), 0, c->stream, a);
-    else hipLaunchKernelGGL((k_dense<3, false>), grid_for(blocks), dim3(kBlock), 0, c->stream, a);
+  if (c->k >= k + 4) {
+    DenseMfma2Args d;
+    d.amp = c->amp;
+    d.mat = reinterpret_cast<const double2*>(c->scratch);
+    d.col_blocks = amps(c) >> (k + 4);
+    for (int i = 0; i < 6; ++i) {
+      d.pos[i] = i < k ? sorted[i] : 0;
+      d.to_caller[i] = 0;
+      for (int q = 0; q < k; ++q) if (i < k && qubits[q] == sorted[i]) d.to_caller[i] = q;
+    }
+    // k <= 4: a wave takes a few column groups (the matrix image costs a few loads per wave); k = 5, 6: resident
+    // workgroups that walk the column groups (the image is built once per workgroup in LDS: 32 / 128 KiB)
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    if (k <= 4) {
+      const u64 waves = (d.col_blocks + 3) / 4;
+      const unsigned grid = (unsigned)std::min<u64>(std::max<u64>((waves + 3) / 4, 1), 1u << 20);
+      if (k == 3) { if (nt) launch_dense_mfma2<3, true, 256>(d, grid, c->stream); else launch_dense_mfma2<3, false, 256>(d, grid, c->stream); }
+      else        { if (nt) launch_dense_mfma2<4, true, 256>(d, grid, c->stream); else launch_dense_mfma2<4, false, 256>(d, grid, c->stream); }
+    } else if (k == 5) {
+      const unsigned grid = (unsigned)std::min<u64>(std::max<u64>((d.col_blocks + 3) / 4, 1), (u64)cus * 4);
+      if (nt) launch_dense_mfma2<5, true, 256>(d, grid, c->stream); else launch_dense_mfma2<5, false, 256>(d, grid, c->stream);
+    } else {
+      const unsigned grid = (unsigned)std::min<u64>(std::max<u64>((d.col_blocks + 7) / 8, 1), (u64)cus);
+      if (nt) launch_dense_mfma2<6, true, 512>(d, grid, c->stream); else launch_dense_mfma2<6, false, 512>(d, grid, c->stream);
+    }
   } else {
-    if (nt) hipLaunchKernelGGL((k_dense<4, true>), grid_for(blocks), dim3(kBlock), 0, c->stream, a);
-    else hipLaunchKernelGGL((k_dense<4, false>), grid_for(blocks), dim3(kBlock), 0, c->stream, a);
+    DenseSmallArgs a;
+    a.amp = c->amp;
+    a.mat = reinterpret_cast<const double2*>(c->scratch);
+    a.k = k;
+    for (int i = 0; i < 6; ++i) { a.bit[i] = i < k ? qubits[i] : 0; a.pos[i] = i < k ? sorted[i] : 0; }
+    hipLaunchKernelGGL(k_dense_small, dim3((unsigned)(amps(c) >> k)), dim3(64), 0, c->stream, a);
   }
   prof.done(c->stream);
   HIP_TRY(hipGetLastError());
@@ -473,6 +504,14 @@ int qsim_apply_ops_tiled(qsim_chunk* c, int n_ops, const int32_t* nq, const int3
 }
 
 int qsim_last_pass_count(const qsim_chunk* c) { return c ? c->last_passes : -1; }
+
+// Forget the cached pass images (run_fused keeps those of the last few op lists): the next call plans again.  For callers
+// that time a COLD call (bench.py `api_path`) or changed their mind about memory.
+int qsim_plan_cache_clear(void) {
+  std::lock_guard<std::mutex> lock(g_plan_cache_mu);
+  g_plan_cache.clear();
+  return QSIM_OK;
+}
 
 static_assert(sizeof(TileArgs) == QSIM_PASS_IMAGE_BYTES, "pass image = the kernel-argument block of k_tile");
 

@@ -144,7 +144,7 @@ class DeviceChunk:
         _lib.check(_lib.load().qsim_apply_2q(self._h, int(qa), int(qb), p))
 
     def apply_fused_k(self, qubits, M: np.ndarray) -> None:
-        """Dense k-qubit block (qsim_apply_fused_k, k <= 4): M is 2^k x 2^k, M[out, in], pattern bit i <-> qubits[i] --
+        """Dense k-qubit block (qsim_apply_fused_k, k <= 6): M is 2^k x 2^k, M[out, in], pattern bit i <-> qubits[i] --
         v3's `_apply_combined_matrix` (parallel_gate_applicator.py:315-385) on the dense state."""
         q = np.asarray(qubits, dtype=np.int32)
         m = np.ascontiguousarray(M, dtype=np.complex128)

@@ -41,8 +41,8 @@ class ParallelGateApplicator:
         return state
 
     def apply_combined_matrix(self, state: DeviceChunk, qubits: list[int], M: np.ndarray) -> DeviceChunk:
-        """v3's `_apply_combined_matrix` (parallel_gate_applicator.py:315-385) for a DENSE 2^k x 2^k matrix (k <= 4),
-        M[out, in], pattern bit i <-> qubits[i]: one launch of the dense k-qubit kernel (qsim_apply_fused_k; k = 3, 4: a matrix
+        """v3's `_apply_combined_matrix` (parallel_gate_applicator.py:315-385) for a DENSE 2^k x 2^k matrix (k <= 6),
+        M[out, in], pattern bit i <-> qubits[i]: one launch of the dense k-qubit kernel (qsim_apply_fused_k; k = 3 .. 6: a matrix
         product on the matrix cores).  For a tensor product of 1q gates prefer `apply_gates_parallel` (butterflies inside a
         fused pass)."""
         state.apply_fused_k(qubits, M)

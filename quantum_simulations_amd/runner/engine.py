@@ -246,15 +246,25 @@ class SingleGpuEngine:
         # random unitaries on low / middle / high / mixed index bits above the 128-byte line
         rng = np.random.default_rng(4)
         dense = {}
-        for k in (3, 4):
-            sets = [list(range(3, 3 + k)), list(range(10, 10 + k)), list(range(n - k, n)), [5, 14, n - 2] + ([n - 9] if k == 4 else [])]
+        MFMA_F64_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (MI355X_MICROARCH.md)
+        for k in (3, 4, 5, 6):
+            mixed = [5, 14, n - 2, n - 9, 8, 11][:k]
+            sets = [list(range(3, 3 + k)), list(range(10, 10 + k)), list(range(n - k, n)), mixed, list(range(k))]
             sets = [qs for qs in sets if max(qs) < n and len(set(qs)) == k]
             M = np.linalg.qr(rng.standard_normal((1 << k, 1 << k)) + 1j * rng.standard_normal((1 << k, 1 << k)))[0]
             ms = [timed(lambda qs=qs: dev.apply_fused_k(qs, M)) for qs in sets]
             fr = [32 * N / (t * 1e-3) / 8.0e12 for t in ms]
-            dense[f"k={k}"] = {"qubit_sets": sets, "ms": [round(t, 4) for t in ms], "frac_of_8TBps": [round(f, 4) for f in fr],
-                               "flop_per_amplitude": 8 * (1 << k),
-                               "kernel": f"k_dense_mfma<{k}> (v_mfma_f64_16x16x4_f64, 16 blocks per wave and step, in place)"}
+            flop = 8.0 * (1 << k) * N                         # 2^k complex multiply-adds per amplitude
+            tf = [flop / (t * 1e-3) / 1e12 for t in ms]
+            # which unit bounds the kernel at this size: the matrix cores when the flops at their peak take longer than the
+            # bytes at the HBM peak (k = 6: 512 flop per amplitude = 7.0 ms against 4.3 ms at 30 qubits)
+            bound = "mfma" if flop / (MFMA_F64_PEAK_TFLOPS * 1e12) > 32.0 * N / 8.0e12 else "hbm"
+            dense[f"k={k}"] = {"qubit_sets": sets, "sets_are": ["low", "middle", "high", "mixed", "line bits 0.." + str(k - 1)][:len(sets)],
+                               "ms": [round(t, 4) for t in ms], "frac_of_8TBps": [round(f, 4) for f in fr],
+                               "flop_per_amplitude": 8 * (1 << k), "achieved_TFLOPs": [round(x, 2) for x in tf],
+                               "frac_of_mfma_f64_peak": [round(x / MFMA_F64_PEAK_TFLOPS, 4) for x in tf], "bound": bound,
+                               "kernel": f"k_dense_mfma2<{k}> (v_mfma_f64_16x16x4_f64, 16 blocks per wave and step, in place; "
+                                         + ("matrix image in LDS" if k >= 5 else "matrix image in registers") + ")"}
         norm2 = dev.norm2()
         if dev is not self.state:
             dev.close()

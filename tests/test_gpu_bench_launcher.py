@@ -58,9 +58,10 @@ def test_single_gpu_line_carries_the_contract_fields():
     assert d["parity_max_abs_diff_vs_cpu_prefix"] < 1e-10 and "invalid" not in d
     sweep = d["sweep30"]                         # (config 3's section, here at 20 qubits: one launch per gate and target)
     assert set(sweep["rows"]) == {"H(q)", "T(q)", "CNOT(q,q+1)", "CNOT(0,q)"} and len(sweep["rows"]["H(q)"]["frac_of_8TBps"]) == 20
-    for k in (3, 4):                             # ... and the dense blocks on the matrix cores
+    for k in (3, 4, 5, 6):                       # ... and the dense blocks on the matrix cores
         blocks = sweep["dense_blocks"][f"k={k}"]
-        assert len(blocks["qubit_sets"]) == 4 and all(f > 0 for f in blocks["frac_of_8TBps"]) and "mfma" in blocks["kernel"]
+        assert len(blocks["qubit_sets"]) == 5 and all(f > 0 for f in blocks["frac_of_8TBps"]) and "mfma" in blocks["kernel"]
+        assert blocks["bound"] == ("mfma" if k == 6 else "hbm") and all(x > 0 for x in blocks["achieved_TFLOPs"])
     assert abs(sweep["norm2_after"] - 1.0) < 1e-10
     # what ONE call of the drop-in entry points costs, next to the steady-state value; item 7: the
     # streaming ceiling seen in this run and the layout facts at the top level; ADVICE r04: the timed plan itself is checked

@@ -113,15 +113,17 @@ def test_config3_every_target_amplitudes_30q(hip):
 
 
 def test_dense_blocks_on_the_matrix_cores_at_30_qubits(hip):
-    """qsim_apply_fused_k at full size (k_dense_mfma: 16 GiB, the streaming instantiation, real offsets beyond 2^32): dense
-    random unitaries on 3 and 4 qubits -- low, high, mixed and line bits, in the caller's (unsorted) order -- against the
+    """qsim_apply_fused_k at full size (k_dense_mfma2: 16 GiB, the streaming instantiation, real offsets beyond 2^32): dense
+    random unitaries on 3 to 6 qubits -- low, high, mixed and line bits, in the caller's (unsorted) order -- against the
     same contraction on the host for sampled blocks (every sampled amplitude has its 2^k - 1 partners sampled)."""
     n = 30
     dev = hip.DeviceChunk.empty(n)
     dev.init_random(31)
     rng = np.random.default_rng(3131)
     run_len = 64
-    for qubits in ([29, 3, 17], [28, 29, 27], [5, 4, 3, 6], [29, 26, 27, 28], [12, 29, 4, 20], [1, 25, 0, 9]):
+    for qubits in ([29, 3, 17], [28, 29, 27], [5, 4, 3, 6], [29, 26, 27, 28], [12, 29, 4, 20], [1, 25, 0, 9], [2, 0, 1],
+                   [7, 29, 3, 18, 11], [2, 27, 0, 1, 14], [29, 25, 28, 26, 27], [21, 4, 9, 29, 13, 6], [1, 0, 2, 3, 5, 4],
+                   [29, 24, 26, 28, 25, 27]):
         k = len(qubits)
         M = np.linalg.qr(rng.standard_normal((1 << k, 1 << k)) + 1j * rng.standard_normal((1 << k, 1 << k)))[0]
         groups = _sample_runs(n, qubits, rng, runs=24)

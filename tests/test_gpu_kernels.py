@@ -758,7 +758,8 @@ def test_plan_cache_reuses_plans_and_tells_op_lists_apart(hip):
 
 def test_dense_k_qubit_block_against_the_oracle(hip):
     """qsim_apply_fused_k (v3's fused block as a genuine 2^k x 2^k contraction, parallel_gate_applicator.py:315-385):
-    random dense unitaries on 1-4 qubits in random order -- line bits included -- on chunks of 4 to 2^20 amplitudes, on a
+    random dense unitaries on 1-6 qubits in random order -- line bits included -- on chunks of 4 to 2^20 amplitudes (below
+    2^(k+4) amplitudes: the one-workgroup-per-block form; from there on the matrix cores, k = 5 / 6 with the matrix in LDS), on a
     small view of a 512 MiB parent (the streaming instantiation), the tensor-product block of v3 through it, and the
     argument checks."""
     from quantum_simulations_amd.parallel_gate_applicator import ParallelGateApplicator, tensor_product_single_qubits
@@ -769,11 +770,14 @@ def test_dense_k_qubit_block_against_the_oracle(hip):
     for n in (2, 4, 7, 11, 16, 20):
         psi0 = _rand_state(n, 500 + n)
         dev = hip.DeviceChunk.from_numpy(psi0)
-        for k in range(1, min(4, n) + 1):
-            for trial in range(6 if n <= 16 else 2):
+        for k in range(1, min(6, n) + 1):
+            for trial in range(6 if n <= 16 else 3):
                 qs = [int(q) for q in rng.choice(n, size=k, replace=False)]
                 if trial == 0:
                     qs = list(range(k))                      # all inside one 128-byte line (k <= 3) / the lowest bits
+                elif trial == 1 and k >= 3:
+                    qs = [int(q) for q in rng.permutation(list(range(3)) + [int(x) for x in rng.choice(np.arange(3, n), size=k - 3, replace=False)])] \
+                        if n - 3 >= k - 3 else qs            # the whole line + others, the caller's order shuffled
                 M = unitary(1 << k)
                 want = psi0.copy()
                 orc.apply_kq(want, qs, M)
@@ -785,7 +789,7 @@ def test_dense_k_qubit_block_against_the_oracle(hip):
     parent = hip.DeviceChunk.empty(25)
     view = parent.view(3 << 14, 14)
     psi0 = _rand_state(14, 9)
-    for qs in ([3, 9, 12], [13, 5, 8, 10], [0, 6, 11]):
+    for qs in ([3, 9, 12], [13, 5, 8, 10], [0, 6, 11], [4, 12, 7, 3, 9], [13, 3, 8, 5, 11, 6]):
         M = unitary(1 << len(qs))
         want = psi0.copy()
         orc.apply_kq(want, qs, M)
@@ -813,8 +817,8 @@ def test_dense_k_qubit_block_against_the_oracle(hip):
         dev.apply_fused_k([0, n, 3], np.eye(8))
     with pytest.raises(ValueError):
         dev.apply_fused_k([0, 1, 1], np.eye(8))
-    with pytest.raises(ValueError):
-        dev.apply_fused_k([0, 1, 2, 3, 4], np.eye(32))
+    with pytest.raises(ValueError, match="1 <= k <= 6"):
+        dev.apply_fused_k([0, 1, 2, 3, 4, 5, 6], np.eye(128))
     with pytest.raises(ValueError):
         dev.apply_fused_k([0, 1, 2], np.eye(4))
     dev.close()
