@@ -504,15 +504,36 @@ __global__ __launch_bounds__(THREADS) void k_dense_mfma2(const DenseMfma2Args a)
     off[m] = o;
   }
   const u64 lane_part = ((u64)(g & 1) << a.pos[0]) | ((u64)(g >> 1) << a.pos[1]);
-  const u64 n_waves = (u64)gridDim.x * (THREADS / 64);
-  for (u64 cb = (u64)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6); cb < a.col_blocks; cb += n_waves) {   // (wave-uniform)
-    u64 c = cb * 16 + (u64)j;
+  // Column groups of a wave: the workgroups are dealt round-robin over the 8 XCDs, so workgroup b works in the b % 8-th
+  // contiguous eighth of the column groups (one XCD's L2 sees one region) and the waves of an XCD stride through it.
+  const u64 bid = (u64)blockIdx.y * gridDim.x + blockIdx.x, n_blocks = (u64)gridDim.x * gridDim.y;
+  const bool split = (n_blocks & 7) == 0 && (a.col_blocks & 7) == 0;
+  const u64 region = split ? a.col_blocks >> 3 : a.col_blocks;
+  const u64 region_base = split ? (bid & 7) * region : 0;
+  const u64 stride = (split ? n_blocks >> 3 : n_blocks) * (THREADS / 64);
+  u64 cb = (split ? bid >> 3 : bid) * (THREADS / 64) + (threadIdx.x >> 6);          // (wave-uniform)
+  auto column_ptr = [&](u64 col_block) -> double2* {
+    u64 c = (region_base + col_block) * 16 + (u64)j;
 #pragma unroll
     for (int i = 0; i < K; ++i) { const int p = a.pos[i]; c = ((c >> p) << (p + 1)) | (c & ((1ull << p) - 1)); }
-    double2* const p0 = a.amp + (c | lane_part);
-    double2 x[MU];
+    return a.amp + (c | lane_part);
+  };
+  if (cb >= region) return;
+  double2* p0 = column_ptr(cb);
+  double2 x[MU];
 #pragma unroll
-    for (int m = 0; m < MU; ++m) x[m] = ld_amp<NT>(p0 + off[m]);
+  for (int m = 0; m < MU; ++m) x[m] = ld_amp<NT>(p0 + off[m]);
+  for (;;) {
+    // the NEXT column group's amplitudes are requested before this one's products start: their latency hides behind the
+    // MFMAs (K = 5, 6: 64 / 256 of them per group)
+    const u64 cb_next = cb + stride;
+    const bool more = cb_next < region;               // (wave-uniform)
+    double2* const p1 = more ? column_ptr(cb_next) : p0;
+    double2 xn[MU];
+    if (more) {
+#pragma unroll
+      for (int m = 0; m < MU; ++m) xn[m] = ld_amp<NT>(p1 + off[m]);
+    }
     qs_double4_t acc[TT];
 #pragma unroll
     for (int t = 0; t < TT; ++t) acc[t] = qs_double4_t{0.0, 0.0, 0.0, 0.0};
@@ -547,6 +568,11 @@ __global__ __launch_bounds__(THREADS) void k_dense_mfma2(const DenseMfma2Args a)
     for (int t = 0; t < TT; ++t)
 #pragma unroll
       for (int h = 0; h < 2; ++h) st_amp<NT>(p0 + off[2 * t + h], make_double2(acc[t][2 * h], acc[t][2 * h + 1]));
+    if (!more) break;
+    cb = cb_next;
+    p0 = p1;
+#pragma unroll
+    for (int m = 0; m < MU; ++m) x[m] = xn[m];
   }
 }
 

@@ -454,14 +454,14 @@ int qsim_apply_fused_k(qsim_chunk* c, int k, const int32_t* qubits, const double
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
     if (k <= 4) {
       const u64 waves = (d.col_blocks + 3) / 4;
-      const unsigned grid = (unsigned)std::min<u64>(std::max<u64>((waves + 3) / 4, 1), 1u << 20);
+      const unsigned grid = (unsigned)std::min<u64>(((std::max<u64>((waves + 3) / 4, 1) + 7) & ~7ull), 1u << 20);   // (whole octets: one region per XCD)
       if (k == 3) { if (nt) launch_dense_mfma2<3, true, 256>(d, grid, c->stream); else launch_dense_mfma2<3, false, 256>(d, grid, c->stream); }
       else        { if (nt) launch_dense_mfma2<4, true, 256>(d, grid, c->stream); else launch_dense_mfma2<4, false, 256>(d, grid, c->stream); }
     } else if (k == 5) {
-      const unsigned grid = (unsigned)std::min<u64>(std::max<u64>((d.col_blocks + 3) / 4, 1), (u64)cus * 4);
+      const unsigned grid = (unsigned)std::min<u64>((std::max<u64>((d.col_blocks + 3) / 4, 1) + 7) & ~7ull, (u64)cus * 4);
       if (nt) launch_dense_mfma2<5, true, 256>(d, grid, c->stream); else launch_dense_mfma2<5, false, 256>(d, grid, c->stream);
     } else {
-      const unsigned grid = (unsigned)std::min<u64>(std::max<u64>((d.col_blocks + 7) / 8, 1), (u64)cus);
+      const unsigned grid = (unsigned)std::min<u64>((std::max<u64>((d.col_blocks + 7) / 8, 1) + 7) & ~7ull, (u64)cus);
       if (nt) launch_dense_mfma2<6, true, 512>(d, grid, c->stream); else launch_dense_mfma2<6, false, 512>(d, grid, c->stream);
     }
   } else {

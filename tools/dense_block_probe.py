@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""HBM rate of the dense k-qubit block kernel (qsim_apply_fused_k) at n qubits: k = 3, 4 on low / middle / high / mixed
-index bits, median of 5 (HIP events), as a fraction of the 8 TB/s peak of the 32 B x 2^n a launch moves.
+"""Rate of the dense k-qubit block kernel (qsim_apply_fused_k) at n qubits: k = 3 .. 6 on low / middle / high / mixed /
+line index bits, median of 5 (HIP events), as a fraction of the 8 TB/s peak of the 32 B x 2^n a launch moves and as
+Tflop/s of its 8 * 2^k flop per amplitude against the 78.6 Tflop/s fp64 matrix peak.  With the probe build and
+QSIM_DENSE_FORM=0 the round-4 kernels run (k <= 4): the A/B partner.
     python tools/dense_block_probe.py [n]"""
 import sys
 from pathlib import Path
@@ -14,8 +16,14 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(1)
 dev = DeviceChunk.empty(n)
 dev.init_random(7)
-for qs in ([3, 4, 5], [10, 11, 12], [n - 3, n - 2, n - 1], [5, 14, n - 2], [0, 1, 2], [3, 4, 5, 6], [9, 13, 17, 21], [n - 4, n - 3, n - 2, n - 1],
-           [4, 12, 20, n - 1], [0, 1, 2, 3]):
+import os
+old_form = os.environ.get("QSIM_DENSE_FORM") == "0"
+sets = [[3, 4, 5], [10, 11, 12], [n - 3, n - 2, n - 1], [5, 14, n - 2], [0, 1, 2], [3, 4, 5, 6], [9, 13, 17, 21], [n - 4, n - 3, n - 2, n - 1],
+        [4, 12, 20, n - 1], [0, 1, 2, 3]]
+if not old_form:
+    sets += [[3, 4, 5, 6, 7], [10, 11, 12, 13, 14], list(range(n - 5, n)), [5, 14, n - 2, n - 9, 8], [0, 1, 2, 3, 4], [0, 1, 2, 12, n - 1],
+             [3, 4, 5, 6, 7, 8], [10, 11, 12, 13, 14, 15], list(range(n - 6, n)), [5, 14, n - 2, n - 9, 8, 11], [0, 1, 2, 3, 4, 5], [0, 1, 2, 12, 20, n - 1]]
+for qs in sets:
     k = len(qs)
     M = np.linalg.qr(rng.standard_normal((1 << k, 1 << k)) + 1j * rng.standard_normal((1 << k, 1 << k)))[0]
     dev.apply_fused_k(qs, M)
@@ -26,6 +34,7 @@ for qs in ([3, 4, 5], [10, 11, 12], [n - 3, n - 2, n - 1], [5, 14, n - 2], [0, 1
         dev.apply_fused_k(qs, M)
         ts.append(dev.time_end())
     ms = float(np.median(ts))
-    print(f"k={k} qubits {qs}: {ms:.3f} ms  frac {32 * 2 ** n / (ms * 1e-3) / 8e12:.3f}", flush=True)
+    tf = 8.0 * (1 << k) * 2 ** n / (ms * 1e-3) / 1e12
+    print(f"k={k} qubits {qs}: {ms:.3f} ms  frac of HBM peak {32 * 2 ** n / (ms * 1e-3) / 8e12:.3f}  {tf:.1f} Tflop/s = {tf / 78.6:.3f} of the fp64 matrix peak", flush=True)
 print("norm2", dev.norm2())
 dev.close()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Matrix-core counters of the dense-block kernels (k_dense_mfma) on tools/dense_block_probe.py at 30 qubits: separate
+# Matrix-core counters of the dense-block kernels (k_dense_mfma2, k = 3 .. 6) on tools/dense_block_probe.py at 30 qubits: separate
 # rocprofv3 --pmc passes (kernel trace only), summary -> gpurun_out/<tag>_dense_mfma_counters.json
 #   bash tools/dense_mfma_counters.sh <tag>
 set -e
@@ -8,7 +8,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 export TMPDIR=/tmp
 cd /tmp
 i=0
-for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA" "SQ_INSTS_VALU SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA" "SQ_INSTS_VALU SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/dm_$i -- python3 $R/tools/dense_block_probe.py 30 > /dev/null 2> $R/gpurun_out/dm_$i.err || echo "set '$set' failed"
 done
