@@ -37,10 +37,49 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+T0 = time.time()       # process start: the wall-clock budget of an N > 1 run counts from here
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 PARITY_TOL = 1e-10
 NORM_TOL = 1e-9
 ALLOWED_ENV: set = set()                 # no QSIM_* variable is read by anything this script times
+
+
+class SectionBudget:
+    """Wall-clock bookkeeping of an N > 1 run (the driver gives one command a fixed time limit): every section's elapsed
+    seconds go to stderr as it starts, OPTIONAL sections are skipped -- and named in the line -- once `limit_s` seconds of
+    the process are gone.  `agree`: a collective max over the ranks, so that every rank takes the same decision (a section
+    that some ranks enter and others skip would hang in its first collective)."""
+
+    def __init__(self, limit_s: float, t0: float | None = None, clock=time.time, agree=None, log=None):
+        self.limit_s, self.t0, self.clock, self.agree = float(limit_s), (clock() if t0 is None else t0), clock, agree
+        self.log = log or (lambda msg: print(msg, file=sys.stderr, flush=True))
+        self.sections, self.skipped, self._open = [], [], None
+
+    def elapsed(self) -> float:
+        e = self.clock() - self.t0
+        return float(self.agree(e)) if self.agree is not None else e
+
+    def begin(self, name: str, optional: bool = False) -> bool:
+        now = self.elapsed()
+        self.end(now)
+        if optional and now > self.limit_s:
+            self.skipped.append(name)
+            self.log(f"bench.py: [{now:6.1f} s] SKIPPED {name} (the {self.limit_s:.0f} s budget is spent)")
+            return False
+        self.log(f"bench.py: [{now:6.1f} s] {name}")
+        self._open = (name, now)
+        return True
+
+    def end(self, now: float | None = None) -> None:
+        if self._open is not None:
+            now = self.elapsed() if now is None else now
+            self.sections.append({"name": self._open[0], "seconds": round(now - self._open[1], 2)})
+            self._open = None
+
+    def report(self) -> dict:
+        self.end()
+        return {"limit_s": self.limit_s, "sections": self.sections, "skipped": self.skipped,
+                "total_s": round(self.clock() - self.t0, 1)}
 
 
 def parse_args():
@@ -77,6 +116,13 @@ def parse_args():
                          "communicator (qsim_comm_exchange, C ABI)")
     ap.add_argument("--no-amplitude-check", action="store_true",
                     help="N > 1: skip the one-GPU reference runs behind the per-shard fingerprint comparison")
+    ap.add_argument("--budget-seconds", type=float, default=400.0,
+                    help="N > 1: optional sections (re-layout measurements, fused on / off, the other exchange API, the one-GPU "
+                         "run at the same local size) are skipped, and named in the line, once this much wall time is gone")
+    ap.add_argument("--no-relayout-pipeline", action="store_true",
+                    help="N > 1: plain fused re-layouts (whole slabs, one group, waited for before the shard is read): isolates "
+                         "an ordering problem of the piece pipeline from a wrong schedule")
+    ap.add_argument("--ab-steps", type=int, default=3, help="N > 1: steps of the short A/B regions (fused re-layout off, other exchange API)")
     return ap.parse_args()
 
 
@@ -477,10 +523,18 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
         threading.Thread(target=heartbeat, daemon=True).start()
     circuit = gen.random_1q_cx_circuit(n, depth=args.depth)
     n_gates = len(circuit["gates"])
-    engine = make_engine(n, world, rank, local_rank, mode=args.mode, rehearsal=args.rehearsal, exchange=args.exchange)
+    engine = make_engine(n, world, rank, local_rank, mode=args.mode, rehearsal=args.rehearsal, exchange=args.exchange,
+                         pipeline_relayout=not args.no_relayout_pipeline)
+    budget = SectionBudget(args.budget_seconds, t0=T0, agree=engine.max_over_ranks,
+                           log=(lambda msg: print(msg, file=sys.stderr, flush=True)) if rank == 0 else (lambda msg: None))
+    budget.begin("plan (start layout search, stage boundaries + tile passes of every execution)")
     engine.init_zero_state()
-    plan = engine.plan(circuit, repeats=args.warmup + args.steps)
+    ab_steps = max(1, args.ab_steps)
+    t_plan = time.perf_counter()
+    plan = engine.plan(circuit, repeats=args.warmup + args.steps + 2 * ab_steps)
+    plan_seconds = time.perf_counter() - t_plan
     layout_info = getattr(engine, "layout_info", None)
+    budget.begin("warm-up + the timed steps")
     for _ in range(args.warmup):
         engine.execute(plan)
     engine.barrier()
@@ -498,9 +552,42 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
     passes = engine.passes_per_step(plan)
     if abs(norm2 - 1.0) > NORM_TOL:
         invalid.append(f"|norm2 - 1| = {abs(norm2 - 1.0):.3e} > {NORM_TOL}")
+    dom0 = max(prof, key=lambda e: e["total_ms"]) if prof else None
+    pass_ms = dom0["total_ms"] / dom0["launches"] if dom0 else None
+
+    def timed_steps(count: int) -> float:
+        engine.barrier()
+        t = time.perf_counter()
+        for _ in range(count):
+            engine.execute(plan)
+        engine.barrier()
+        return engine.max_over_ranks(time.perf_counter() - t) / count * 1e3
+
+    # ---- what a re-layout costs on THIS machine, by m (replaces the modelled RELAYOUT_PASSES of the planner) ----------
+    relayout_measured = None
+    if budget.begin("re-layout measurements (m = 1 .. p, there and back)", optional=True):
+        relayout_measured = engine.measure_relayouts(reps=1)
+        for rec in relayout_measured:
+            ms = rec["exchange_event_ms"] if rec["exchange_event_ms"] is not None else None
+            rec["relayout_in_pass_units"] = round(ms / pass_ms, 2) if (ms is not None and pass_ms) else None
+            rec["modelled_pass_units"] = engine.RELAYOUT_PASSES.get(rec["m"])
+    # ---- re-layouts fused into the neighbouring passes: on (the timed region) / off ------------------------------------
+    fused_ab = None
+    if budget.begin("fused re-layout on / off", optional=True):
+        on_ms = timed_steps(ab_steps)
+        engine.fuse_relayout = False
+        off_ms = timed_steps(ab_steps)
+        off_passes = engine.passes_per_step(plan)
+        engine.fuse_relayout = True
+        fused_ab = {"steps_each": ab_steps, "ms_per_step_fused": round(on_ms, 3), "ms_per_step_unfused": round(off_ms, 3),
+                    "hbm_passes_fused": passes, "hbm_passes_unfused": off_passes}
+        n2 = engine.norm2()
+        if abs(n2 - 1.0) > NORM_TOL:
+            invalid.append(f"after the fused on / off region: |norm2 - 1| = {abs(n2 - 1.0):.3e}")
 
     configs = None
     if not args.no_configs:
+        budget.begin("configs 4 / 5 and the amplitude checks against one-GPU runs")
         # config 5 closed forms; config 4 staged / unstaged and the random 1q+CX circuit: every amplitude, through
         # per-shard fingerprints, against a one-GPU run of the same circuit on rank 0
         configs = engine.run_baseline_configs(gen, check_amplitudes=not args.no_amplitude_check)
@@ -520,11 +607,53 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
                 d = run.get("fingerprint_max_abs_diff_vs_single_gpu")
                 if d is not None and not d < PARITY_TOL:
                     invalid.append(f"{key} {label}: shard fingerprints differ from the one-GPU run by {d:.3e} > {PARITY_TOL}")
+    # ---- the OTHER exchange API on the same schedule (torch P2P <-> the library's own communicator) ---------------------
+    # Its failure is reported as a string and does not invalidate the line (the timed region above stands on its own); an
+    # error that only some ranks see can still hang the job in the next collective, which is why this section comes last
+    # of the collective ones and the line so far goes to stderr first.
+    other_api = "cabi" if args.exchange == "torch" else "torch"
+    other = {"exchange_api": other_api, "ran": False}
+    if args.rehearsal and other_api == "cabi":
+        other["skipped"] = "rehearsal: the library's RCCL communicator needs one rank per GPU"
+    elif budget.begin(f"the other exchange API ({other_api}): GHZ+QFT closed form + {ab_steps} timed steps", optional=True):
+        if rank == 0:
+            print("bench.py: partial line before the second exchange API: " + json.dumps(
+                {"value": round(n_gates * args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 3), "n_gpus": world,
+                 "relayout_measured": relayout_measured, "fused_relayout_ab": fused_ab}), file=sys.stderr, flush=True)
+        try:
+            from quantum_simulations_amd.runner.distributed import DistributedEngine
+            engine._flush_local()
+            engine.barrier()
+            if hasattr(engine.backend, "release_buffers"):
+                engine.backend.release_buffers()                     # (room for the second engine's three buffers)
+            e2 = DistributedEngine(n, world, rank, local_rank, mode=args.mode, exchange=other_api, init_process_group=False,
+                                   pipeline_relayout=not args.no_relayout_pipeline)
+            qft = gen.generate_ghz_qft(n)
+            e2.init_zero_state()
+            e2.execute(e2.plan(qft))
+            err = e2.closed_form_error("ghz_qft")
+            e2.init_zero_state()
+            plan2 = e2.plan(circuit, repeats=1 + ab_steps)
+            e2.execute(plan2)
+            e2.barrier()
+            t2 = time.perf_counter()
+            for _ in range(ab_steps):
+                e2.execute(plan2)
+            e2.barrier()
+            ms2 = e2.max_over_ranks(time.perf_counter() - t2) / ab_steps * 1e3
+            n2 = e2.norm2()
+            other.update(ran=True, ms_per_step=round(ms2, 3), gate_apps_per_s=round(n_gates / (ms2 * 1e-3), 2), steps=ab_steps,
+                         ghz_qft_max_abs_err_vs_closed_form=err, norm2=n2, hbm_passes_per_step=e2.passes_per_step(plan2),
+                         ok=bool(err < PARITY_TOL and abs(n2 - 1.0) < NORM_TOL))
+            e2.backend.close()
+        except Exception as e:                                       # noqa: BLE001 -- reported, not fatal
+            other["error"] = f"{type(e).__name__}: {e}"[:500]
     # the same workload family on ONE GPU at the same local size (rank 0, outside the timed region, the other
     # ranks wait): per-GPU work is what weak scaling holds fixed, and the N = 1 default of this script is the
     # 28-qubit metric configuration, not a 30-local-qubit one
     single = None
-    if rank == 0 and not args.no_single_reference:
+    run_single_ref = (not args.no_single_reference) and budget.begin("one GPU at the same local size (rank 0)", optional=True)
+    if rank == 0 and run_single_ref:
         from quantum_simulations_amd.runner.engine import SingleGpuEngine
         e1 = SingleGpuEngine(k, device=local_rank, mode=args.mode)
         c1 = gen.random_1q_cx_circuit(k, depth=args.depth)
@@ -572,7 +701,11 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
         "dtype": "f64", "data": "synthetic",
         # what carried the transfers of this line: "rccl" (one rank per GPU over xGMI) or "gloo-rehearsal" (ranks sharing
         # the visible GPUs, host-staged: NOT a multi-GPU number); exchange_api: who posts them (torch P2P / the C ABI)
-        "exchange": engine.exchange, "exchange_api": engine.exchange_api,
+        "exchange": engine.exchange, "exchange_api": engine.exchange_api, "relayout_pipeline": not args.no_relayout_pipeline,
+        "plan_seconds": round(plan_seconds, 3),
+        # measured on this machine: an all-to-all over m rank bits (ms, GB/s per rank, in units of one fused pass); the
+        # step with the re-layouts NOT fused into the neighbouring passes; the same schedule through the other exchange API
+        "relayout_measured": relayout_measured, "fused_relayout_ab": fused_ab, "other_exchange_api": other,
         "exchange_ms_per_step_max_over_ranks": (round(xgmi["exchange_ms_max_over_ranks"] / args.steps, 3)
                                                 if xgmi.get("exchange_ms_max_over_ranks") is not None else None),
         "config": {"workload": f"{n}-qubit random 1q+CX circuit depth {args.depth} (seed 20260228), "
@@ -597,6 +730,7 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
         "kernel_breakdown": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof],
         "baseline_configs": configs,
     }
+    out["wall_clock"] = budget.report()
     engine.close()
     return out, invalid
 

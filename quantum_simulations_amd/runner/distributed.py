@@ -384,7 +384,7 @@ class DistributedEngine:
                  mode: str = "fused", backend=None, staging: bool = True,
                  staging_method: str = "tiles", init_process_group: bool = True,
                  relayout_pieces: int = 4, min_piece_qubits: int = 20, fuse_relayout: bool = True,
-                 rehearsal: bool = False, exchange: str = "torch", layout: str = "auto"):
+                 rehearsal: bool = False, exchange: str = "torch", layout: str = "auto", pipeline_relayout: bool = True):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -463,6 +463,12 @@ class DistributedEngine:
         # receive buffer -- no separate pack / unpack pass of the shard.  `_state_in` = (buffer, local bits) while
         # the shard lives in a receive buffer in slab layout (None: in "state", index order).
         self.fuse_relayout = fuse_relayout
+        # pipeline_relayout = False (bench.py --no-relayout-pipeline): the plain form of a fused re-layout -- whole slabs
+        # stored by one launch, ONE group posted, and the host path WAITS for it before anything reads the shard (no pieces,
+        # nothing `_inflight`).  The in-flight piece pipeline has only ever run on one GPU and under gloo rehearsal
+        # (ADVICE r04): a first multi-GPU run that fails can be repeated with this switch to tell a wrong schedule from an
+        # ordering problem between the transfer stream and the partial launches.
+        self.pipeline_relayout = bool(pipeline_relayout)
         self._state_in = None
         # ... and, while the pieces of that re-layout may still be on the links, `_inflight` = (posted groups, timer): the
         # next reader of the shard consumes them piece by piece (its first pass starts on the tiles whose pieces are there)
@@ -964,6 +970,20 @@ class DistributedEngine:
             # consumed buffer is the new home.  Three shard-sized buffers per rank in every case.
             from_recv = self._state_in is not None and self._state_in[0] == "buf1"
             ops, self._pending = self._pending, []
+            if not self.pipeline_relayout:
+                # plain form: the slabs are stored by this call, one group carries them whole, and it is waited for
+                self._drain_inflight()
+                self._run_local(ops, dst=("buf0", loc, "buf1", mine), parts=0)
+                rname = "state" if (from_recv and self.backend.own_slab_in_state()) else "buf1"
+                timer = self._comm_timer(send)
+                posted = self._post("buf0", rname, [(peer, d * slab, slab) for d, peer in peers])
+                self._finish(posted)
+                self._comm_done(timer)
+                if rname == "state":
+                    self.backend.swap_names("state", "buf1")
+                    self.home_moves += 1
+                self._state_in = ("buf1", list(loc))
+                return
             self._run_local(ops, dst=("buf0", loc, "buf1", mine), parts=self._split_parts())
             rname = "state" if (from_recv and self.backend.own_slab_in_state()) else "buf1"
             timer = self._comm_timer(send)
@@ -1268,6 +1288,43 @@ class DistributedEngine:
                     rec[label]["fingerprint_max_abs_diff_vs_single_gpu"] = d
                     rec[label]["pass_1e-10"] = bool(d < 1e-10)
             out[key] = rec
+        return out
+
+    def measure_relayouts(self, reps: int = 2) -> list:
+        """Collective.  What an all-to-all over m rank bits costs on THIS machine, m = 1 .. p, measured on the idle shard
+        (whatever state it holds: every re-layout is made twice, there and back, so the state and the layout are the same
+        afterwards): local bits k-1, k-2, ... trade places with rank bits 0, 1, ...  With nothing queued around it a
+        re-layout is a pack pass, the exchange (piece by piece, all peers at once) and an unpack pass; reported per m:
+        host-clock milliseconds (max over ranks) of the whole thing, device-event milliseconds of the exchange alone (RCCL
+        runs: stream events from the first post to the last arrival; max over ranks), bytes per rank and the rate they
+        give.  Replaces the modelled RELAYOUT_PASSES once a multi-GPU node has run it (bench.py prints
+        `relayout_in_pass_units`)."""
+        import time
+        out = []
+        shard_bytes = 16 << self.k
+        for m in range(1, self.p + 1):
+            pairs = [[self.k - 1 - i, self.k + i] for i in range(m)]
+            if self.k - m < 3:
+                break
+            wall, events = [], []
+            for _ in range(2 * max(1, reps)):
+                self._flush_local()
+                self.barrier()
+                self.reset_comm_stats()
+                t0 = time.perf_counter()
+                self.relayout(pairs)
+                self._flush_local()
+                self.barrier()
+                wall.append(self.max_over_ranks(time.perf_counter() - t0) * 1e3)
+                events.append(self.comm_stats().get("exchange_ms_max_over_ranks"))
+            sent = shard_bytes - (shard_bytes >> m)
+            ev = [e for e in events if e]
+            best_ev = min(ev) if ev else None
+            out.append({"m": m, "local_bits": [pr[0] for pr in pairs], "bytes_sent_per_rank": sent, "pieces": self._relayout_pieces(self.k - m),
+                        "wall_ms_pack_exchange_unpack": round(min(wall), 3), "exchange_event_ms": None if best_ev is None else round(best_ev, 3),
+                        "exchange_GBps_per_rank": None if best_ev is None else round(sent / (best_ev * 1e-3) / 1e9, 1),
+                        "wall_GBps_per_rank": round(sent / (min(wall) * 1e-3) / 1e9, 1), "repeats": 2 * max(1, reps)})
+        self.reset_comm_stats()
         return out
 
     def comm_stats(self) -> dict:

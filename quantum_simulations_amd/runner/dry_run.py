@@ -115,5 +115,8 @@ def main(world: int, rank: int, k: int) -> int:
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "local_qubits": k, "n_qubits": k + world.bit_length() - 1,
                           "ok": rc == 0 and all(d["ok"] for d in docs), "exchange": "none (schedule only, gloo control plane)",
+                          # the fields a run on devices fills in (bench.py run_multi): measured re-layouts by m, the step with
+                          # unfused re-layouts, the same schedule through the other exchange API, the wall-clock sections
+                          "relayout_measured": None, "fused_relayout_ab": None, "other_exchange_api": None, "wall_clock": None,
                           "workloads": docs}), flush=True)
     return rc

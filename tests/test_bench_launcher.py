@@ -79,3 +79,41 @@ def test_gpu_count_must_be_a_power_of_two():
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "3", "--dry-run"], cwd=ROOT, env=_clean_env(),
                          capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "power of two" in out.stderr
+
+
+def test_wall_clock_budget_skips_optional_sections_and_says_so():
+    """an N > 1 run prints every section's start to stderr and skips the OPTIONAL ones -- naming them
+    in the line -- once the budget is spent; every rank must take the same decision (`agree` = a max over the ranks)."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    now = [1000.0]
+    logged, agreed = [], []
+
+    def agree(x):
+        agreed.append(x)
+        return x + 5.0                      # (another rank is five seconds further on: its clock decides)
+    b = bench.SectionBudget(400.0, t0=1000.0, clock=lambda: now[0], agree=agree, log=logged.append)
+    assert b.begin("plan")
+    now[0] += 30
+    assert b.begin("timed steps")
+    now[0] += 300
+    assert b.begin("re-layout measurements", optional=True)          # 330 + 5 s < 400
+    now[0] += 66
+    assert not b.begin("fused on / off", optional=True)              # 396 + 5 s > 400: skipped ...
+    assert b.begin("configs")                                         # ... a mandatory section still runs
+    now[0] += 50
+    assert not b.begin("other exchange API", optional=True)
+    rep = b.report()
+    assert rep["skipped"] == ["fused on / off", "other exchange API"] and rep["limit_s"] == 400.0
+    assert [s_["name"] for s_ in rep["sections"]] == ["plan", "timed steps", "re-layout measurements", "configs"]
+    assert [s_["seconds"] for s_ in rep["sections"]] == [30.0, 300.0, 66.0, 50.0]
+    assert len(agreed) >= 6 and any("SKIPPED fused on / off" in ln for ln in logged) and any("timed steps" in ln for ln in logged)
+
+
+def test_dry_run_line_names_the_fields_a_device_run_fills_in():
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run"], cwd=ROOT,
+                         env=_clean_env(), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    doc = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    for key in ("relayout_measured", "fused_relayout_ab", "other_exchange_api", "wall_clock"):
+        assert key in doc and doc[key] is None

@@ -31,6 +31,27 @@ def test_four_ranks_sharing_one_gpu_through_the_launcher():
         for label in labels:
             assert cfg[key][label]["fingerprint_max_abs_diff_vs_single_gpu"] < 1e-10
     assert doc["roofline"]["kernel"].startswith("k_tile") and doc["value"] > 0
+    # one N > 1 run answers the open multi-GPU questions -- measured re-layouts by m (null rates where only
+    # RCCL events can tell), the step with unfused re-layouts, the other exchange API (skipped in rehearsal: says why), and
+    # the wall-clock sections
+    rl = doc["relayout_measured"]
+    assert [r["m"] for r in rl] == [1, 2] and all(r["wall_ms_pack_exchange_unpack"] > 0 and r["bytes_sent_per_rank"] > 0 for r in rl)
+    assert all(r["exchange_event_ms"] is None and r["modelled_pass_units"] in (10.4, 5.2) for r in rl)      # (gloo rehearsal: no device events)
+    ab = doc["fused_relayout_ab"]
+    assert ab["ms_per_step_fused"] > 0 and ab["ms_per_step_unfused"] > 0 and ab["hbm_passes_unfused"] >= ab["hbm_passes_fused"]
+    assert doc["other_exchange_api"]["exchange_api"] == "cabi" and doc["other_exchange_api"]["ran"] is False and "rehearsal" in doc["other_exchange_api"]["skipped"]
+    wc = doc["wall_clock"]
+    assert wc["skipped"] == [] and wc["total_s"] > 0 and [s_["name"] for s_ in wc["sections"]][:2] == [
+        "plan (start layout search, stage boundaries + tile passes of every execution)", "warm-up + the timed steps"]
+    assert doc["relayout_pipeline"] is True and doc["plan_seconds"] > 0
+    # ... and with no budget at all every optional section is skipped and named, the line stays valid
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--rehearsal", "--local-qubits", "20", "--steps", "1",
+                          "--warmup", "1", "--budget-seconds", "0", "--no-configs", "--no-relayout-pipeline"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-5000:]
+    doc = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][0])
+    assert doc["relayout_measured"] is None and doc["fused_relayout_ab"] is None and doc["single_gpu_same_local_size"] is None
+    assert len(doc["wall_clock"]["skipped"]) == 3 and doc["relayout_pipeline"] is False and "invalid" not in doc
 
 
 def test_single_gpu_line_carries_the_contract_fields():
