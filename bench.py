@@ -71,8 +71,9 @@ class SectionBudget:
         return True
 
     def end(self, now: float | None = None) -> None:
+        """(no collective here: `report` runs on rank 0 alone)"""
         if self._open is not None:
-            now = self.elapsed() if now is None else now
+            now = (self.clock() - self.t0) if now is None else now
             self.sections.append({"name": self._open[0], "seconds": round(now - self._open[1], 2)})
             self._open = None
 

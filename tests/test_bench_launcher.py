@@ -103,7 +103,9 @@ def test_wall_clock_budget_skips_optional_sections_and_says_so():
     assert b.begin("configs")                                         # ... a mandatory section still runs
     now[0] += 50
     assert not b.begin("other exchange API", optional=True)
+    calls = len(agreed)
     rep = b.report()
+    assert len(agreed) == calls, "report() runs on rank 0 alone: it must not enter a collective"
     assert rep["skipped"] == ["fused on / off", "other exchange API"] and rep["limit_s"] == 400.0
     assert [s_["name"] for s_ in rep["sections"]] == ["plan", "timed steps", "re-layout measurements", "configs"]
     assert [s_["seconds"] for s_ in rep["sections"]] == [30.0, 300.0, 66.0, 50.0]
