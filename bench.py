@@ -99,6 +99,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-sweep", action="store_true", help="skip the per-target sweeps (config 3)")
     ap.add_argument("--no-api-path", action="store_true", help="N = 1: skip the one-call timings of single_node.run / Driver.run_circuit")
+    ap.add_argument("--no-plan-check", action="store_true",
+                    help="N = 1: skip the timed plan's fingerprint check against an identity-layout execution (profiling runs: "
+                         "keeps other plans' passes out of the kernel statistics)")
     ap.add_argument("--sweep-qubits", type=int, default=30)
     ap.add_argument("--fused-qubits", type=int, default=30,
                     help="N = 1: size of the second fused run (`fused30` sub-record; 0 = off)")
@@ -387,7 +390,7 @@ def run_single(args, k: int) -> tuple[dict, list[str]]:
     # norm check): one execution of `plan` from |0..0>, its layout-aware fingerprint, and the same of a plan made with
     # layout = "identity" (index bit = qubit, the library's own tiles)
     timed_plan_check = None
-    if args.mode == "fused":
+    if args.mode == "fused" and not args.no_plan_check:
         seed = 20260504
         engine.init_zero_state()
         engine.execute(plan)

@@ -31,6 +31,9 @@ def klass(name: str):
     m = re.search(r"k_gate<(\d),", name)
     if m:
         return f"k_gate<{m.group(1)}>"
+    m = re.search(r"k_dense_mfma2<(\d)", name)
+    if m:
+        return f"k_dense_mfma2<{m.group(1)}>"
     m = re.search(r"k_tile", name)
     if m:
         return "k_tile"
