@@ -662,7 +662,7 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
         e1 = SingleGpuEngine(k, device=local_rank, mode=args.mode)
         c1 = gen.random_1q_cx_circuit(k, depth=args.depth)
         e1.init_zero_state()
-        reps1 = max(5, min(args.steps, 10))
+        reps1 = max(6, min(args.steps, 10))          # (2 + 6 executions: enough for the engine's layout search, as in the N = 1 line)
         p1 = e1.plan(c1, repeats=2 + reps1)
         for _ in range(2):
             e1.execute(p1)
