@@ -248,7 +248,7 @@ class SingleGpuEngine:
         dense = {}
         MFMA_F64_PEAK_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (MI355X_MICROARCH.md)
         for k in (3, 4, 5, 6):
-            mixed = [5, 14, n - 2, n - 9, 8, 11][:k]
+            mixed = [5, 14, n - 2, n - 9, 8, 12][:k]
             sets = [list(range(3, 3 + k)), list(range(10, 10 + k)), list(range(n - k, n)), mixed, list(range(k))]
             sets = [qs for qs in sets if max(qs) < n and len(set(qs)) == k]
             M = np.linalg.qr(rng.standard_normal((1 << k, 1 << k)) + 1j * rng.standard_normal((1 << k, 1 << k)))[0]
