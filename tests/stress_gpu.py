@@ -35,6 +35,27 @@ while time.time() - t0 < budget:
         err = float(np.max(np.abs(dev.download() - want)))
         worst = max(worst, err)
         assert err < 1e-10, (n, seed, fused, err)
+    if n >= 8:               # the caller names the tiles of the first passes (qsim_apply_ops_tiled): ANY masks -- useful,
+        hints = []           # useless (no op fits: ignored), too wide, inside the line -- must leave the result alone
+        for _ in range(int(rng.integers(1, 6))):
+            width = int(rng.integers(0, 11))
+            hints.append(sum(1 << int(b) for b in rng.choice(n, size=min(width, n), replace=False)))
+        dev.upload(psi0)
+        dev.apply_ops_tiled(ops, np.array(hints, dtype=np.uint64))
+        err = float(np.max(np.abs(dev.download() - want)))
+        worst = max(worst, err)
+        assert err < 1e-10, ("tiled", n, seed, hints, err)
+    if n >= 3:               # dense k-qubit blocks, k <= 6 (small chunks: one workgroup per block; else the matrix cores)
+        k = int(rng.integers(3, min(6, n) + 1))
+        qs = [int(q) for q in rng.choice(n, size=k, replace=False)]
+        M = np.linalg.qr(rng.standard_normal((1 << k, 1 << k)) + 1j * rng.standard_normal((1 << k, 1 << k)))[0]
+        wantk = psi0.copy()
+        orc.apply_kq(wantk, qs, M)
+        dev.upload(psi0)
+        dev.apply_fused_k(qs, M)
+        err = float(np.max(np.abs(dev.download() - wantk)))
+        worst = max(worst, err)
+        assert err < 1e-10, ("dense", n, seed, qs, err)
     if n >= 4:               # the same op list with a re-layout fused into its ends (qsim_apply_ops_io), random slab bits
         m = int(rng.integers(1, min(3, n - 1) + 1))
         bits_in = [int(b) for b in rng.choice(n, size=m, replace=False)]
@@ -52,7 +73,12 @@ while time.time() - t0 < budget:
         split = int(rng.integers(0, 4))       # 0: one call stores the slabs; else the split form, pieces stored in random order
         three = own >= 0 and rng.random() < 0.5      # three buffers: the own slab goes into the consumed source buffer -- or,
         own_buf = src if three else keep             # when one pass does everything, into the chunk itself (own_slab_in_chunk)
-        dev.apply_ops_io(ops, src=(src, bits_in), dst=(dst, bits_out, own_buf if own >= 0 else None, own), parts=-(1 << split) if split else 0)
+        io_hints = None
+        if rng.random() < 0.5:                       # ... with the tiles of the first passes named by the caller (any masks)
+            io_hints = np.array([sum(1 << int(b) for b in rng.choice(n, size=min(int(rng.integers(0, 10)), n), replace=False))
+                                 for _ in range(int(rng.integers(1, 5)))], dtype=np.uint64)
+        dev.apply_ops_io(ops, src=(src, bits_in), dst=(dst, bits_out, own_buf if own >= 0 else None, own), parts=-(1 << split) if split else 0,
+                         tiles=io_hints)
         if split:
             parts = dev.pending_parts()
             slab_amps = (1 << n) >> m
