@@ -740,12 +740,13 @@ class DistributedEngine:
                                        "relayouts": scored[best][2], "index": best}}
         return cands[best]
 
-    LAYOUT_MIN_REPEATS = 8          # layout "auto": plans for fewer executions try 4 start layouts, not 16 (the search is host time)
+    LAYOUT_MIN_REPEATS = 8          # layout "auto": plans for fewer executions try 2 start layouts, not 33 (the search is host time)
 
     def choose_initial_layout_tiles(self, cd: dict, repeats: int = 1, n_candidates: int | None = None, seed: int = 20260504) -> list:
         """Staging method "tiles": l2p for a state that is still |0..0>.  Candidates: the identity, and assignments that put
         the p qubits whose FIRST use as a target comes last on the rank bits (Belady at time zero) with the other qubits
-        in random order (which three sit on the line bits, members of every tile, moves the pass count).  Each is priced by
+        in random order (which three sit on the line bits, members of every tile, moves the pass count), one in eight any
+        assignment at all.  Each is priced by
         the partition planner itself -- passes + re-layouts in pass units of the first execution, and of a second one from
         the layout the first leaves behind when the plan will be repeated -- in parallel threads.  The planner names its
         tiles to the library, so what is priced is what every rank runs: no twin execution, no collective.  Deterministic."""
@@ -755,7 +756,7 @@ class DistributedEngine:
         t0 = time.perf_counter()
         n, k, p = self.n, self.k, self.p
         if n_candidates is None:
-            n_candidates = 16 if self._plan_effort_high else 1
+            n_candidates = 32 if self._plan_effort_high else 1
         packed = self._packed_ops(cd)
         first = [1 << 60] * n
         for i, tg in enumerate(packed.targets):
@@ -765,6 +766,9 @@ class DistributedEngine:
         rng = np.random.default_rng(seed)
         cands = [list(range(n))]
         for c in range(n_candidates):
+            if c and c % 8 == 7:                      # (one in eight: any assignment at all)
+                cands.append([int(x) for x in rng.permutation(n)])
+                continue
             rest = [int(q) for q in (rng.permutation(n) if c else np.arange(n)) if q not in far]
             l2p = [0] * n
             for i, q in enumerate(rest):
