@@ -403,6 +403,7 @@ class DistributedEngine:
         self.plan_threads = 8
         self._plan_effort_high = False
         self.place_slots = True      # staging method "tiles", fresh state: local slots placed by the tile-cost model
+        self.place_slots_min_k = 26  # (the model was fitted at 28 / 30 qubits; smaller shards are cache resident: tests lower it)
         self.use_tile_hints = True
         # rehearsal (explicit argument; bench.py --rehearsal): several ranks share the visible GPU(s), each with its shard
         # in HBM and the real HIP kernels, and exchange through host-staged gloo -- RCCL refuses two ranks on one
@@ -824,7 +825,7 @@ class DistributedEngine:
             steps, l2p = self._steps_from(cd, l2p)
             executions.append(steps)
             mappings.append(list(l2p))
-        if was_fresh and self.place_slots and self._tiles_method() and self.k >= 26:
+        if was_fresh and self.place_slots and self._tiles_method() and self.k >= self.place_slots_min_k:
             # |0..0> looks the same under every assignment of qubits to index bits: the local slots of the whole chain of
             # executions are put on the index bits whose tiles have the best DRAM pattern (partition_plan.place_slots)
             import time

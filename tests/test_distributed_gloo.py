@@ -66,7 +66,10 @@ def _worker(rank, world, port, n, staging_modes, errors, moves=None):
             eng = DistributedEngine(n, world, rank, backend=CpuShardBackend(n - p),
                                     staging=staging, staging_method=method, fuse_relayout=not rest or rest[0],
                                     relayout_pieces=(4, 2, 1)[mode_no % 3], min_piece_qubits=1,
-                                    layout="search" if mode_no % 2 == 0 else "identity")
+                                    layout="search" if mode_no % 2 == 0 else "identity",
+                                    pipeline_relayout=not (method == "tiles" and mode_no % 2 == 1))
+            if method == "tiles":
+                eng.place_slots_min_k = 8        # (the slot placement by the tile-cost model, on shards far below its 26 qubits)
             for name, cd in _circuits(n).items():
                 want = orc.simulate(validate_circuit_dict(cd))
                 eng.init_zero_state()
@@ -95,6 +98,8 @@ def _worker(rank, world, port, n, staging_modes, errors, moves=None):
                 assert err2 < 1e-12, f"{name} repeat staging={staging}/{method}: {err2}"
                 if method == "tiles" and n - p >= 8:     # (the partition planner really planned this run)
                     assert eng.last_partition_plan["passes"] >= 1 and eng.last_partition_plan["segments"]
+                    if mode_no % 2 == 0:                 # ... and with a searched start layout the local slots were placed
+                        assert "slot_placement" in (eng.layout_info or {}), eng.layout_info
             if moves is not None:
                 moves.put(eng.home_moves)
             eng.backend.close()
@@ -164,7 +169,7 @@ def test_tiles_staging_world2_4_8_gloo():
     >= 8 local qubits (the library's pass builder plans them): 2 / 4 / 8 ranks, every circuit family, two executions, with
     and without fused re-layouts, searched and identity start layouts -- amplitudes against the oracle at 1e-12."""
     _run(2, 10, [(True, "tiles"), (True, "tiles", False)])
-    _run(4, 10, [(True, "tiles"), (True, "tiles")])
+    _run(4, 10, [(True, "tiles"), (True, "tiles")])          # (the second mode: plain, unpipelined fused re-layouts)
     _run(8, 11, [(True, "tiles"), (True, "tiles", False)])
 
 
