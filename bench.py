@@ -126,6 +126,8 @@ def parse_args():
     ap.add_argument("--no-relayout-pipeline", action="store_true",
                     help="N > 1: plain fused re-layouts (whole slabs, one group, waited for before the shard is read): isolates "
                          "an ordering problem of the piece pipeline from a wrong schedule")
+    ap.add_argument("--other-api-timeout", type=float, default=150.0,
+                    help="N > 1: seconds the second exchange API's section may take before the line is printed without it and the ranks exit")
     ap.add_argument("--ab-steps", type=int, default=3, help="N > 1: steps of the short A/B regions (fused re-layout off, other exchange API)")
     return ap.parse_args()
 
@@ -611,47 +613,6 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
                 d = run.get("fingerprint_max_abs_diff_vs_single_gpu")
                 if d is not None and not d < PARITY_TOL:
                     invalid.append(f"{key} {label}: shard fingerprints differ from the one-GPU run by {d:.3e} > {PARITY_TOL}")
-    # ---- the OTHER exchange API on the same schedule (torch P2P <-> the library's own communicator) ---------------------
-    # Its failure is reported as a string and does not invalidate the line (the timed region above stands on its own); an
-    # error that only some ranks see can still hang the job in the next collective, which is why this section comes last
-    # of the collective ones and the line so far goes to stderr first.
-    other_api = "cabi" if args.exchange == "torch" else "torch"
-    other = {"exchange_api": other_api, "ran": False}
-    if args.rehearsal and other_api == "cabi":
-        other["skipped"] = "rehearsal: the library's RCCL communicator needs one rank per GPU"
-    elif budget.begin(f"the other exchange API ({other_api}): GHZ+QFT closed form + {ab_steps} timed steps", optional=True):
-        if rank == 0:
-            print("bench.py: partial line before the second exchange API: " + json.dumps(
-                {"value": round(n_gates * args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 3), "n_gpus": world,
-                 "relayout_measured": relayout_measured, "fused_relayout_ab": fused_ab}), file=sys.stderr, flush=True)
-        try:
-            from quantum_simulations_amd.runner.distributed import DistributedEngine
-            engine._flush_local()
-            engine.barrier()
-            if hasattr(engine.backend, "release_buffers"):
-                engine.backend.release_buffers()                     # (room for the second engine's three buffers)
-            e2 = DistributedEngine(n, world, rank, local_rank, mode=args.mode, exchange=other_api, init_process_group=False,
-                                   pipeline_relayout=not args.no_relayout_pipeline)
-            qft = gen.generate_ghz_qft(n)
-            e2.init_zero_state()
-            e2.execute(e2.plan(qft))
-            err = e2.closed_form_error("ghz_qft")
-            e2.init_zero_state()
-            plan2 = e2.plan(circuit, repeats=1 + ab_steps)
-            e2.execute(plan2)
-            e2.barrier()
-            t2 = time.perf_counter()
-            for _ in range(ab_steps):
-                e2.execute(plan2)
-            e2.barrier()
-            ms2 = e2.max_over_ranks(time.perf_counter() - t2) / ab_steps * 1e3
-            n2 = e2.norm2()
-            other.update(ran=True, ms_per_step=round(ms2, 3), gate_apps_per_s=round(n_gates / (ms2 * 1e-3), 2), steps=ab_steps,
-                         ghz_qft_max_abs_err_vs_closed_form=err, norm2=n2, hbm_passes_per_step=e2.passes_per_step(plan2),
-                         ok=bool(err < PARITY_TOL and abs(n2 - 1.0) < NORM_TOL))
-            e2.backend.close()
-        except Exception as e:                                       # noqa: BLE001 -- reported, not fatal
-            other["error"] = f"{type(e).__name__}: {e}"[:500]
     # the same workload family on ONE GPU at the same local size (rank 0, outside the timed region, the other
     # ranks wait): per-GPU work is what weak scaling holds fixed, and the N = 1 default of this script is the
     # 28-qubit metric configuration, not a 30-local-qubit one
@@ -678,10 +639,80 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
                   "amplitude_updates_per_s": len(c1["gates"]) * reps1 * float(1 << k) / dt1}
         e1.close()
     engine.barrier()
+    out = None
+    if rank == 0:
+        out = multi_line(args, world, k, n, n_gates, dt, prof, passes, layout_info, plan_seconds, relayout_measured, fused_ab, single,
+                         norm2, xgmi, configs, engine)
+    # ---- the OTHER exchange API on the same schedule (torch P2P <-> the library's own communicator) ---------------------
+    # It runs LAST, when the line of everything above is complete, under a watchdog: a path that has never run on more than
+    # one GPU may hang in a collective, and a hung job must not lose the measurements it already has -- after
+    # `--other-api-timeout` seconds rank 0 prints the line as it stands (the section marked as abandoned) and every rank exits.
+    import threading
+    other_api = "cabi" if args.exchange == "torch" else "torch"
+    other = {"exchange_api": other_api, "ran": False}
+    section_done = threading.Event()
+
+    def abandon():
+        if section_done.wait(args.other_api_timeout):
+            return
+        if rank == 0:
+            other["error"] = f"no result after {args.other_api_timeout:.0f} s: the section was abandoned (a hang in a collective?)"
+            out["other_exchange_api"] = other
+            out["wall_clock"] = budget.report()
+            if invalid:
+                out["invalid"] = invalid
+            print(json.dumps(out), flush=True)
+        os._exit(1 if invalid else 0)
+    hang_hook = os.environ.get("BENCH_TEST_OTHER_API_HANG") == "1"      # (tests/test_gpu_bench_launcher.py: a section that never returns)
+    if args.rehearsal and other_api == "cabi" and not hang_hook:
+        other["skipped"] = "rehearsal: the library's RCCL communicator needs one rank per GPU"
+    elif budget.begin(f"the other exchange API ({other_api}): GHZ+QFT closed form + {max(1, args.ab_steps)} timed steps", optional=True):
+        threading.Thread(target=abandon, daemon=True).start()
+        ab_steps = max(1, args.ab_steps)
+        try:
+            from quantum_simulations_amd.runner.distributed import DistributedEngine
+            engine._flush_local()
+            engine.barrier()
+            if hang_hook:
+                time.sleep(10 ** 6)
+            if hasattr(engine.backend, "release_buffers"):
+                engine.backend.release_buffers()                     # (room for the second engine's three buffers)
+            e2 = DistributedEngine(n, world, rank, local_rank, mode=args.mode, exchange=other_api, init_process_group=False,
+                                   pipeline_relayout=not args.no_relayout_pipeline)
+            qft = gen.generate_ghz_qft(n)
+            e2.init_zero_state()
+            e2.execute(e2.plan(qft))
+            err = e2.closed_form_error("ghz_qft")
+            e2.init_zero_state()
+            plan2 = e2.plan(circuit, repeats=1 + ab_steps)
+            e2.execute(plan2)
+            e2.barrier()
+            t2 = time.perf_counter()
+            for _ in range(ab_steps):
+                e2.execute(plan2)
+            e2.barrier()
+            ms2 = e2.max_over_ranks(time.perf_counter() - t2) / ab_steps * 1e3
+            n2 = e2.norm2()
+            other.update(ran=True, ms_per_step=round(ms2, 3), gate_apps_per_s=round(n_gates / (ms2 * 1e-3), 2), steps=ab_steps,
+                         ghz_qft_max_abs_err_vs_closed_form=err, norm2=n2, hbm_passes_per_step=e2.passes_per_step(plan2),
+                         ok=bool(err < PARITY_TOL and abs(n2 - 1.0) < NORM_TOL))
+            e2.backend.close()
+        except Exception as e:                                       # noqa: BLE001 -- reported, not fatal
+            other["error"] = f"{type(e).__name__}: {e}"[:500]
+        section_done.set()
+    section_done.set()
     if rank != 0:
         engine.close()
         return None, invalid
+    out["other_exchange_api"] = other
+    out["wall_clock"] = budget.report()
+    engine.close()
+    return out, invalid
 
+
+def multi_line(args, world, k, n, n_gates, dt, prof, passes, layout_info, plan_seconds, relayout_measured, fused_ab, single, norm2, xgmi,
+               configs, engine) -> dict:
+    """The N > 1 line (rank 0) of everything but the second exchange API."""
     dom = max(prof, key=lambda e: e["total_ms"]) if prof else None
     roofline = None
     kernel_ms = sum(e["total_ms"] for e in prof)
@@ -709,7 +740,7 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
         "plan_seconds": round(plan_seconds, 3),
         # measured on this machine: an all-to-all over m rank bits (ms, GB/s per rank, in units of one fused pass); the
         # step with the re-layouts NOT fused into the neighbouring passes; the same schedule through the other exchange API
-        "relayout_measured": relayout_measured, "fused_relayout_ab": fused_ab, "other_exchange_api": other,
+        "relayout_measured": relayout_measured, "fused_relayout_ab": fused_ab, "other_exchange_api": None,
         "exchange_ms_per_step_max_over_ranks": (round(xgmi["exchange_ms_max_over_ranks"] / args.steps, 3)
                                                 if xgmi.get("exchange_ms_max_over_ranks") is not None else None),
         "config": {"workload": f"{n}-qubit random 1q+CX circuit depth {args.depth} (seed 20260228), "
@@ -734,9 +765,7 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
         "kernel_breakdown": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof],
         "baseline_configs": configs,
     }
-    out["wall_clock"] = budget.report()
-    engine.close()
-    return out, invalid
+    return out
 
 
 # ---------------------------------------------------------------------------------- launcher-free N > 1

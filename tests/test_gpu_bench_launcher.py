@@ -52,6 +52,16 @@ def test_four_ranks_sharing_one_gpu_through_the_launcher():
     doc = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][0])
     assert doc["relayout_measured"] is None and doc["fused_relayout_ab"] is None and doc["single_gpu_same_local_size"] is None
     assert len(doc["wall_clock"]["skipped"]) == 3 and doc["relayout_pipeline"] is False and "invalid" not in doc
+    # ... and a second-exchange-API section that never returns (test hook) does not lose the line: the watchdog prints it
+    # with the section marked as abandoned and every rank exits 0
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--rehearsal", "--local-qubits", "20", "--steps", "1",
+                          "--warmup", "1", "--no-configs", "--ab-steps", "1", "--other-api-timeout", "5"], cwd=ROOT,
+                         env=dict(env, BENCH_TEST_OTHER_API_HANG="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-5000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    doc = json.loads(lines[0])
+    assert "abandoned" in doc["other_exchange_api"]["error"] and doc["value"] > 0 and "invalid" not in doc
 
 
 def test_single_gpu_line_carries_the_contract_fields():
