@@ -174,6 +174,26 @@ def test_single_pass_both_ends_and_argument_checks():
     small = DeviceChunk.empty(10)
     with pytest.raises(ValueError):
         state.apply_ops_io(ops, src=(small, [5]))
+    # qsim_ops_io carries its size; a host built against another layout of the struct (a shorter, older one; a
+    # zeroed one) is refused with a message that says what to do, instead of being read past its end
+    import ctypes as C
+
+    from quantum_simulations_amd import _lib
+    from quantum_simulations_amd.kernel.device import pack_ops
+    nq, qs, mats = pack_ops(ops)
+    for bad_size in (0, C.sizeof(_lib.OpsIo) - 16, C.sizeof(_lib.OpsIo) + 8):
+        io = _lib.OpsIo()
+        io.struct_size = bad_size
+        io.dst, io.dst_m, io.own_pattern = buf0._h, 1, -1
+        io.dst_bits[0] = 13
+        with pytest.raises(ValueError, match="struct_size"):
+            _lib.check(_lib.load().qsim_apply_ops_io(state._h, len(nq), nq.ctypes.data_as(C.c_void_p), qs.ctypes.data_as(C.c_void_p),
+                                                     mats.ctypes.data_as(C.c_void_p), C.byref(io), None))
+    # ... and the tiles of the first passes may be named through it (any masks: useless ones are ignored)
+    state.upload(psi0)
+    hints = np.array([(1 << 5) | (1 << 9) | 0b11111 << 6, 1 << 13, 0], dtype=np.uint64)
+    assert state.apply_ops_io(ops, dst=(buf0, [13], buf1, 1), tiles=hints) >= 1
+    np.testing.assert_allclose(buf0.download()[:1 << (k - 1)], _slabs(want, [13])[0], rtol=0, atol=1e-12)
     for c in (state, buf0, buf1, small):
         c.close()
 
