@@ -140,7 +140,7 @@ def plan_partition(ops, n: int, k: int, min_ops: int = 20, full_width: bool = Tr
         last_need = segments[-1]["needs"][-1] if segments[-1]["needs"] else 0
         # The LAST re-layout can come as early as p local qubits are finished (never a target again): they leave, every
         # global qubit comes in, and nothing will ever wait for a rank bit again -- the ops that wait now join the passes
-        # from here on instead of filling thin ones at the end (GHZ+QFT: 8 -> 6 passes at 33 qubits).
+        # from here on instead of filling thin ones at the end (GHZ+QFT: 8 -> 7 passes at 33 qubits).
         finished = [q for q in range(n) if LINE_BITS <= cur[q] < k and use[q] == never and not (last_need >> int(cur[q])) & 1]
         final_now = waiting and not fresh_segment and len(finished) >= p and segments[-1]["masks"]
         if members and not final_now and (len(members) >= min_ops or not waiting or fresh_segment):
