@@ -84,7 +84,23 @@ class PackedOps:
         return other
 
 
-def _peek(lib, check, packed: PackedOps, k: int, cur, done, members, avoid: int = 0):
+def _peek(lib, check, packed: PackedOps, k: int, cur, done, members, avoid: int = 0, cache: dict | None = None):
+    """(tile mask, needed bits, member ops) of the next pass.  `cache`: planner runs that differ only in their thin-pass
+    threshold make the same decisions up to the first pass whose size lies between the thresholds: the same (layout, done
+    set) is asked again and again."""
+    key = None
+    if cache is not None:
+        key = (cur.tobytes(), done.tobytes(), avoid)
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
+    out = _peek_uncached(lib, check, packed, k, cur, done, members, avoid)
+    if cache is not None:
+        cache[key] = out
+    return out
+
+
+def _peek_uncached(lib, check, packed: PackedOps, k: int, cur, done, members, avoid: int = 0):
     qs = np.ascontiguousarray(cur[packed.labels])
     qs[1::2][packed.one_q] = 0
     mask, need, count = C.c_uint64(), C.c_uint64(), C.c_int32()
@@ -94,7 +110,7 @@ def _peek(lib, check, packed: PackedOps, k: int, cur, done, members, avoid: int 
     return int(mask.value), int(need.value), [int(i) for i in members[:count.value]]
 
 
-def plan_partition(ops, n: int, k: int, min_ops: int = 20, full_width: bool = True, relayout_cost=None) -> dict:
+def plan_partition(ops, n: int, k: int, min_ops: int = 20, full_width: bool = True, relayout_cost=None, cache: dict | None = None) -> dict:
     """ops: [(qubits, U)] (or a PackedOps) on index bits 0..n-1 of the whole state (bits >= k are rank bits), program order.
     -> {"steps", "moved", "passes", "relayouts", "cost", "segments", "min_ops"}: steps in the reference's format in the
     index bits of their time, moved[b] = where the qubit that started on bit b ends, passes = fused passes committed,
@@ -133,7 +149,7 @@ def plan_partition(ops, n: int, k: int, min_ops: int = 20, full_width: bool = Tr
         seg["needs"].append(need)
 
     while not done.all():
-        mask, need, members = _peek(lib, check, packed, k, cur, done, scratch)
+        mask, need, members = _peek(lib, check, packed, k, cur, done, scratch, cache=cache)
         use = next_target_use()
         waiting = any(use[q] != never for q in range(n) if cur[q] >= k)      # an op somewhere waits for a rank bit
         fresh_segment = len(segments) > 1 and not segments[-1]["masks"]      # (a re-layout right behind a re-layout buys nothing)
@@ -251,11 +267,18 @@ def plan_partition_best(ops, n: int, k: int, choices=MIN_OPS_CHOICES, threads: i
     the earlier choice.  Deterministic: every rank of a run computes the same schedule from the same circuit."""
     packed = ops if isinstance(ops, PackedOps) else PackedOps(ops, n)
     jobs = [(m, True) for m in choices]          # (narrow re-layouts never won on the seeded workloads: not tried)
+    # A shared cache of pass-builder answers: the runs agree up to the first pass whose size lies between two thresholds.
+    # In parallel threads (the default) a run only profits from what another has already asked; one after the other
+    # (threads <= 1) the later runs ask little that is new (measured on 8 cores: 25 executions at 33 qubits / 8 ranks planned
+    # in 5.4 s in parallel against 11.5 s in sequence; at 31 qubits / 2 ranks, where the runs hardly differ, 15 s against 8 s).
+    cache: dict = {}
+
+    def run(job):
+        return plan_partition(packed, n, k, min_ops=job[0], full_width=job[1], relayout_cost=relayout_cost, cache=cache)
     if threads > 1 and len(jobs) > 1:
-        results = list(planning_pool(threads).map(
-            lambda j: plan_partition(packed, n, k, min_ops=j[0], full_width=j[1], relayout_cost=relayout_cost), jobs))
+        results = list(planning_pool(threads).map(run, jobs))
     else:
-        results = [plan_partition(packed, n, k, min_ops=m, full_width=fw, relayout_cost=relayout_cost) for m, fw in jobs]
+        results = [run(j) for j in jobs]
     best = min(range(len(results)), key=lambda i: (results[i]["cost"], i))
     out = results[best]
     out["tried"] = [{"min_ops": j[0], "full_width": j[1], "passes": r["passes"], "relayouts": r["relayouts"], "cost": round(r["cost"], 2)}
