@@ -741,7 +741,7 @@ class DistributedEngine:
                                        "relayouts": scored[best][2], "index": best}}
         return cands[best]
 
-    LAYOUT_MIN_REPEATS = 8          # layout "auto": plans for fewer executions try 2 start layouts, not 33 (the search is host time)
+    LAYOUT_MIN_REPEATS = 8          # layout "auto": plans for fewer executions try 2 start layouts, not 17 (the search is host time)
 
     def choose_initial_layout_tiles(self, cd: dict, repeats: int = 1, n_candidates: int | None = None, seed: int = 20260504) -> list:
         """Staging method "tiles": l2p for a state that is still |0..0>.  Candidates: the identity, and assignments that put
@@ -757,7 +757,7 @@ class DistributedEngine:
         t0 = time.perf_counter()
         n, k, p = self.n, self.k, self.p
         if n_candidates is None:
-            n_candidates = 32 if self._plan_effort_high else 1
+            n_candidates = 16 if self._plan_effort_high else 1     # (32 found nothing better on the seeded workloads)
         packed = self._packed_ops(cd)
         first = [1 << 60] * n
         for i, tg in enumerate(packed.targets):
