@@ -6,7 +6,8 @@ layout searched, local slots placed by the tile-cost model).  The op lists rank 
 planning twin of the engine, with the tiles the planner names -- run on ONE shard-sized chunk: same kernels and plans as on
 the node; the exchanges are skipped (the data is meaningless, the timing is not; the slab stores of the fused re-layouts
 are not part of it).
-    python tools/shard_compute_probe.py [N_QUBITS N_RANKS [REPEATS]]"""
+    python tools/shard_compute_probe.py [N_QUBITS N_RANKS [REPEATS [RANK]]]     (RANK: whose op lists; default 0; the last rank
+                                                                               applies every gate with a global control)"""
 import sys
 import time
 from pathlib import Path
@@ -21,6 +22,7 @@ from quantum_simulations_amd.runner.distributed import DistributedEngine, Planni
 
 n, world = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (32, 4)
 repeats = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+rank = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 p = world.bit_length() - 1
 k = n - p
 chunk = DeviceChunk.empty(k)
@@ -32,7 +34,7 @@ for name, cd, reps in (("random 1q+CX depth 40", gen.random_1q_cx_circuit(n, dep
                        ("GHZ+QFT", gen.generate_ghz_qft(n), 1)):
     cd = validate_circuit_dict(cd)
     for label, kw in VARIANTS:
-        eng = DistributedEngine(n, world, 0, backend=PlanningBackend(k), init_process_group=False, **kw)
+        eng = DistributedEngine(n, world, rank, backend=PlanningBackend(k), init_process_group=False, **kw)
         eng.init_zero_state()
         t0 = time.perf_counter()
         plan = eng.plan(cd, repeats=reps)
@@ -60,7 +62,7 @@ for name, cd, reps in (("random 1q+CX depth 40", gen.random_1q_cx_circuit(n, dep
                 best = min(best, time.perf_counter() - t0)
             per_exec.append((passes, len(relayouts), best * 1e3))
         ms = [e[2] for e in per_exec]
-        print(f"n={n} on {world} ranks ({k} local qubits), {name}, {label}: passes / re-layouts per execution "
+        print(f"n={n} on {world} ranks ({k} local qubits), rank {rank}, {name}, {label}: passes / re-layouts per execution "
               f"{[(a, b) for a, b, _ in per_exec]}, compute ms per execution {[round(x, 1) for x in ms]} (mean {np.mean(ms):.1f}, "
               f"{np.mean(ms) / np.mean([e[0] for e in per_exec]):.2f} ms per pass), planning {plan_s:.1f} s, slots {(eng.layout_info or {}).get('slot_placement')}", flush=True)
 chunk.close()
