@@ -354,11 +354,13 @@ def run_single(args, k: int) -> tuple[dict, list[str]]:
     plan_seconds = time.perf_counter() - t_plan
     # the FIRST execution of the plan, by the host clock (cold pass images, first launches): what a caller who runs the
     # circuit once waits for after planning -- `value` below is the steady state of the repeated plan
-    engine.barrier()
-    t_first = time.perf_counter()
-    engine.execute(plan)
-    engine.barrier()
-    first_execution_ms = (time.perf_counter() - t_first) * 1e3
+    first_execution_ms = None
+    if args.warmup > 0:                       # (the first of the W warm-up steps; with --warmup 0 the timed region starts cold)
+        engine.barrier()
+        t_first = time.perf_counter()
+        engine.execute(plan)
+        engine.barrier()
+        first_execution_ms = (time.perf_counter() - t_first) * 1e3
     for _ in range(max(0, args.warmup - 1)):
         engine.execute(plan)
     engine.barrier()
@@ -457,7 +459,7 @@ def run_single(args, k: int) -> tuple[dict, list[str]]:
         # level too: `value` is the steady state AFTER that search
         "layout": "identity" if layout_rec == "identity" else "searched",
         "qubit_layout_seconds": None if layout_rec == "identity" else layout_rec.get("seconds"),
-        "plan_seconds": round(plan_seconds, 3), "first_execution_ms": round(first_execution_ms, 3),
+        "plan_seconds": round(plan_seconds, 3), "first_execution_ms": None if first_execution_ms is None else round(first_execution_ms, 3),
         "amplitude_updates_per_s": n_gates * args.steps * float(1 << n) / dt,
         "sustained": sustained,
         "norm2_after": norm2,
