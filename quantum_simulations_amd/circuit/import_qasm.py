@@ -3,18 +3,28 @@
 v3_hisvsim_spark/hisvsim_repo/QASMBench/ in the reference -- its Python path never reads them).
 
 `qasm_to_dict(text)` -> circuit dict of the circuit contract (wenbo_engine/docs/circuit_contract.md).
-The contract's gates are H X Y Z S T RY R(k) G(p) CNOT SWAP CZ CY CR(k) CU -- there is NO general 1q
-rotation, so only what maps EXACTLY is accepted:
+The contract's gates are H X Y Z S T RY R(k) G(p) CNOT SWAP CZ CY CR(k) CU.  What maps EXACTLY:
 
     h x y z s t ry cx cz cy swap id                 one gate each
     sdg = Z S, tdg = Z S T                          (diagonal, exact)
-    u1 / p (lambda), cu1 / cp (lambda)              when lambda = 2 pi m / 2^K, K <= 48: a product of R(k) / CR(k)
+    u1 / p (lambda), cu1 / cp (lambda)              lambda = 2 pi m / 2^K, K <= 48: a product of R(k) / CR(k)
+    cu1 / cp (any lambda), crz, crx, cry, cu3, ch   the contract's CU with the 2x2 block as its `U` (exact)
     ccx, cswap                                      the standard 15-gate Clifford+T decomposition
     user `gate` definitions                         expanded in place
     barrier, measure (terminal), creg               dropped
 
-Everything else (rx rz u2 u3 rzz ryy crz ch reset if(...) ...) raises ValueError("unsupported gate ...")
-like validate_circuit_dict does for unknown names.  Parity: the importer has no counterpart in the
+and, exact UP TO A GLOBAL PHASE of the whole state (the contract has RY(theta) for every angle, and a rotation about any
+other axis is RY between Cliffords: RX(a) = S^dagger RY(a) S, RZ(a) = (S H)^dagger RY(a) (S H) -- runs of 1q gates are fused
+into one 2x2 before they reach the device, so the extra Cliffords cost nothing there):
+
+    rx rz                                           the SU(2) rotation (qelib1's rz(a) = u1(a) = e^{i a / 2} RZ(a))
+    u3(t, p, l) = e^{i (p + l) / 2} RZ(p) RY(t) RZ(l),  u2(p, l) = u3(pi / 2, p, l),  u / U = u3
+    u1 / p with an angle that is no dyadic fraction of 2 pi: RZ(lambda) (phase e^{i lambda / 2} dropped)
+    rzz(a) = cx; RZ(a) on the target; cx = exp(-i a / 2 Z x Z); rxx, ryy likewise (qelib1's forms carry a phase e^{i a / 2})
+
+A statevector differs from qiskit's by that one unit-modulus factor; probabilities, expectation values and every
+controlled use are unaffected.  Everything else (reset, if(...), opaque, mid-circuit measurement ...) raises
+ValueError("unsupported gate ...") like validate_circuit_dict does for unknown names.  Parity: the importer has no counterpart in the
 reference, so there is no reference fixture for it -- "parity unpinned"; the tests check it against
 explicit matrices on small registers.  Qubit q[i] of the first register is qubit i (bit i of the
 amplitude index: qiskit's and this engine's little-endian convention); further registers follow.
@@ -27,14 +37,16 @@ import re
 _SIMPLE = {"h": "H", "x": "X", "y": "Y", "z": "Z", "s": "S", "t": "T", "cx": "CNOT", "cnot": "CNOT",
            "cz": "CZ", "cy": "CY", "swap": "SWAP"}
 _ARITY = {"h": 1, "x": 1, "y": 1, "z": 1, "s": 1, "t": 1, "sdg": 1, "tdg": 1, "id": 1, "ry": 1, "u1": 1, "p": 1,
-          "cx": 2, "cnot": 2, "cz": 2, "cy": 2, "swap": 2, "cu1": 2, "cp": 2, "ccx": 3, "cswap": 3}
-_NPARAMS = {"ry": 1, "u1": 1, "p": 1, "cu1": 1, "cp": 1}
+          "rx": 1, "rz": 1, "u2": 1, "u3": 1, "u": 1, "U": 1,
+          "cx": 2, "cnot": 2, "cz": 2, "cy": 2, "swap": 2, "cu1": 2, "cp": 2, "crz": 2, "crx": 2, "cry": 2, "cu3": 2, "ch": 2,
+          "rzz": 2, "rxx": 2, "ryy": 2, "ccx": 3, "cswap": 3}
+_NPARAMS = {"ry": 1, "u1": 1, "p": 1, "cu1": 1, "cp": 1, "rx": 1, "rz": 1, "u2": 2, "u3": 3, "u": 3, "U": 3, "crz": 1, "crx": 1,
+            "cry": 1, "cu3": 3, "rzz": 1, "rxx": 1, "ryy": 1}
 _MAX_K = 48
 
 
 def _unsupported(name: str, why: str = "") -> ValueError:
-    return ValueError(f"unsupported gate '{name}'" + (f": {why}" if why else "")
-                      + " (the circuit contract has no general 1-qubit rotation; see import_qasm.py)")
+    return ValueError(f"unsupported gate '{name}'" + (f": {why}" if why else "") + " (see circuit/import_qasm.py for what is read)")
 
 
 # ---- parameter expressions: numbers, pi, + - * / ^, parentheses, unary minus, a few functions ----
@@ -127,9 +139,33 @@ def _phase_powers(name: str, lam: float) -> list[int]:
     raise _unsupported(name, f"angle {lam!r} is not a multiple of 2 pi / 2^k (k <= {_MAX_K})")
 
 
+def _dyadic_or_none(name: str, lam: float):
+    try:
+        return _phase_powers(name, lam)
+    except ValueError:
+        return None
+
+
+def u3_matrix(theta: float, phi: float, lam: float):
+    """qelib1's u3 (OpenQASM 2.0 spec): [[cos t/2, -e^{i l} sin t/2], [e^{i p} sin t/2, e^{i (p + l)} cos t/2]]"""
+    import numpy as np
+    c, s_ = math.cos(theta / 2.0), math.sin(theta / 2.0)
+    return np.array([[c, -complex(math.cos(lam), math.sin(lam)) * s_],
+                     [complex(math.cos(phi), math.sin(phi)) * s_, complex(math.cos(phi + lam), math.sin(phi + lam)) * c]], dtype=np.complex128)
+
+
 def _emit_builtin(name: str, params: list[float], q: list[int], out: list) -> None:
     def g(gate, qubits, **p):
         out.append({"qubits": list(qubits), "gate": gate, "params": p})
+
+    def rz(qubit, a):          # diag(e^{-i a / 2}, e^{i a / 2}) = (S H)^dagger RY(a) (S H): circuit order H, S, RY, S^dagger, H
+        g("H", [qubit]), g("S", [qubit]), g("RY", [qubit], theta=float(a)), g("Z", [qubit]), g("S", [qubit]), g("H", [qubit])
+
+    def rx(qubit, a):          # S^dagger RY(a) S: circuit order S, RY, S^dagger
+        g("S", [qubit]), g("RY", [qubit], theta=float(a)), g("Z", [qubit]), g("S", [qubit])
+
+    def controlled(U):         # the contract's CU: |0><0| x I + |1><1| x U, control = q[0]
+        g("CU", q, U=U, exponent=1)
 
     if name in _SIMPLE:
         g(_SIMPLE[name], q)
@@ -145,11 +181,52 @@ def _emit_builtin(name: str, params: list[float], q: list[int], out: list) -> No
         g("S", q)
         g("T", q)
     elif name in ("u1", "p"):
-        for k in _phase_powers(name, params[0]):
-            g("R", q, k=k)
+        ks = _dyadic_or_none(name, params[0])
+        if ks is not None:
+            for k in ks:
+                g("R", q, k=k)
+        else:                                  # (any other angle: the rotation, its phase e^{i lambda / 2} dropped)
+            rz(q[0], params[0])
     elif name in ("cu1", "cp"):
-        for k in _phase_powers(name, params[0]):
-            g("CR", q, k=k)
+        ks = _dyadic_or_none(name, params[0])
+        if ks is not None:
+            for k in ks:
+                g("CR", q, k=k)
+        else:
+            controlled(u3_matrix(0.0, 0.0, params[0]))
+    elif name == "rz":
+        rz(q[0], params[0])
+    elif name == "rx":
+        rx(q[0], params[0])
+    elif name in ("u3", "u", "U", "u2"):
+        theta, phi, lam = (math.pi / 2.0, params[0], params[1]) if name == "u2" else params
+        rz(q[0], lam)
+        g("RY", q, theta=float(theta))
+        rz(q[0], phi)
+    elif name == "crz":
+        import numpy as np
+        controlled(np.diag([complex(math.cos(params[0] / 2), -math.sin(params[0] / 2)), complex(math.cos(params[0] / 2), math.sin(params[0] / 2))]))
+    elif name == "crx":
+        controlled(u3_matrix(params[0], -math.pi / 2.0, math.pi / 2.0))
+    elif name == "cry":
+        controlled(u3_matrix(params[0], 0.0, 0.0))
+    elif name == "cu3":
+        controlled(u3_matrix(*params))
+    elif name == "ch":
+        import numpy as np
+        controlled(np.array([[1, 1], [1, -1]], dtype=np.complex128) / math.sqrt(2.0))
+    elif name == "rzz":                        # exp(-i a / 2 Z x Z)
+        _emit_builtin("cx", [], q, out)
+        rz(q[1], params[0])
+        _emit_builtin("cx", [], q, out)
+    elif name == "rxx":                        # exp(-i a / 2 X x X) = (H x H) rzz (H x H)
+        g("H", [q[0]]), g("H", [q[1]])
+        _emit_builtin("rzz", params, q, out)
+        g("H", [q[0]]), g("H", [q[1]])
+    elif name == "ryy":                        # exp(-i a / 2 Y x Y): rzz between RX(pi / 2) and RX(-pi / 2) on both qubits
+        rx(q[0], math.pi / 2.0), rx(q[1], math.pi / 2.0)
+        _emit_builtin("rzz", params, q, out)
+        rx(q[0], -math.pi / 2.0), rx(q[1], -math.pi / 2.0)
     elif name == "ccx":
         a, b, c = q
         for nm, qs in (("h", [c]), ("cx", [b, c]), ("tdg", [c]), ("cx", [a, c]), ("t", [c]), ("cx", [b, c]),

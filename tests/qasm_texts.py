@@ -59,3 +59,20 @@ def phase_estimation(t: int, numerator: int) -> str:
         lines += [f"cu1(-pi/{1 << (j - k)}) c[{k}],c[{j}];" for k in range(j)]
         lines.append(f"h c[{j}];")
     return "\n".join(lines)
+
+
+def ising_trotter(n: int, steps: int, seed: int = 3) -> str:
+    """Trotterised transverse-field Ising chain in the shape of QASMBench's ising / qaoa inputs: layers of rzz on a ring,
+    rx and rz with arbitrary angles on every qubit, a u3 and a crz thrown in -- the gates the importer maps through RY
+    between Cliffords and through the contract's CU."""
+    import random
+    rnd = random.Random(seed)
+    lines = [HDR, f"qreg q[{n}];", "h q;"]
+    for _ in range(steps):
+        lines += [f"rzz({rnd.uniform(-1.5, 1.5):.9f}) q[{i}],q[{(i + 1) % n}];" for i in range(n)]
+        lines += [f"rx({rnd.uniform(-3, 3):.9f}) q[{i}];" for i in range(n)]
+        lines += [f"rz({rnd.uniform(-3, 3):.9f}) q[{i}];" for i in range(0, n, 2)]
+        a, b = rnd.sample(range(n), 2)
+        lines.append(f"u3({rnd.uniform(0, 3):.9f},{rnd.uniform(-3, 3):.9f},{rnd.uniform(-3, 3):.9f}) q[{a}];")
+        lines.append(f"crz({rnd.uniform(-3, 3):.9f}) q[{a}],q[{b}];")
+    return "\n".join(lines)

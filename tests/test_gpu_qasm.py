@@ -15,7 +15,7 @@ import pytest
 from oracle import c_oracle, dense_oracle as orc
 from quantum_simulations_amd.circuit.import_qasm import qasm_to_dict
 from quantum_simulations_amd.circuit.io import validate_circuit_dict
-from tests.qasm_texts import bernstein_vazirani, phase_estimation, qft_cu1, ripple_adder
+from tests.qasm_texts import bernstein_vazirani, ising_trotter, phase_estimation, qft_cu1, ripple_adder
 
 pytestmark = pytest.mark.gpu
 
@@ -78,3 +78,12 @@ def test_qft_with_cu1(n, prepare):
 @pytest.mark.parametrize("t,numerator", [(13, 0x0B35), (15, 0x5555)])
 def test_phase_estimation_reads_the_dyadic_phase_exactly(t, numerator):
     _check(phase_estimation(t, numerator), expect_index=numerator | (1 << t))
+
+
+@pytest.mark.parametrize("n,steps", [(14, 6), (18, 4)])
+def test_ising_trotter_with_arbitrary_rotations(n, steps):
+    """rzz / rx / rz / u3 with arbitrary angles (RY between Cliffords, fused to one 2x2 per run before they reach the device)
+    and crz (the contract's CU) through ONE fused call, against the C oracle's gate-by-gate run of the same circuit dict."""
+    cd, got = _check(ising_trotter(n, steps))
+    assert {"RY", "CU", "CNOT"} <= {g["gate"] for g in cd["gates"]}
+    assert abs(float(np.vdot(got, got).real) - 1.0) < 1e-10
