@@ -25,7 +25,28 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         _lib.orc_num_threads.restype = C.c_int
         for name in ("orc_apply_1q", "orc_apply_2q", "orc_apply_1q_pair", "orc_run_ops"):
             getattr(_lib, name).restype = C.c_int
+        # OpenMP's default is every logical CPU of the HOST; a container with a smaller share (the GPU box: 16 cores of a
+        # few hundred) then runs hundreds of spinning threads on its few cores and every gate's barrier takes milliseconds
+        # (a 1 400-gate circuit at 14 qubits: minutes instead of a second).  Start from the share this process really has.
+        _lib.orc_set_threads(C.c_int(max(1, min(_lib.orc_num_threads(), host_core_share()))))
     return _lib
+
+
+def host_core_share() -> int:
+    """Cores this process may really use: min(cpu_count, affinity, cgroup cpu.max quota)."""
+    import os
+    cores = os.cpu_count() or 1
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(cores, 32)
 
 
 def _p(a: np.ndarray):
