@@ -395,8 +395,9 @@ def _long_list_with_a_control_only_qubit(n: int, n_ops: int, seed: int) -> list:
 def test_planning_time_per_pass_is_bounded_on_long_lists():
     """with a control-only qubit every scan of the commutation-aware pass builder walked the whole remaining
     list -- 7.5-12 ms of host time per pass on a 4000-op list, several times the device time of a 28-qubit pass (1.7 ms).
-    The scans now stop `plan_scan_window` waiting ops behind the front (csrc/tile_planner.h).  Budget: 4 ms per pass
-    (measured 1.4-1.6 ms on the build container) -- and no more passes than the unbounded scan needed (100)."""
+    The scans now stop `plan_scan_window` waiting ops behind the front (csrc/tile_planner.h).  Budget: 6 ms per pass
+    (measured 1.4-1.6 ms on the idle build container, up to 4 under a parallel test run; the unbounded scan took 7.5-12)
+    -- and no more passes than the unbounded scan needed (100)."""
     import ctypes as C
     import time
 
@@ -415,7 +416,7 @@ def test_planning_time_per_pass_is_bounded_on_long_lists():
                                      mats.ctypes.data_as(C.c_void_p), None, 0, C.byref(k)))
         best = min(best, time.perf_counter() - t0)
     assert k.value <= 102, k.value
-    assert best / k.value < 4e-3, f"{best / k.value * 1e3:.2f} ms of planning per pass"
+    assert best / k.value < 6e-3, f"{best / k.value * 1e3:.2f} ms of planning per pass"
 
 
 def test_bounded_scan_plans_equal_the_oracle_on_lists_longer_than_the_window():
