@@ -652,13 +652,15 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
     import threading
     other_api = "cabi" if args.exchange == "torch" else "torch"
     other = {"exchange_api": other_api, "ran": False}
-    section_done = threading.Event()
+    section_done, shutdown_done = threading.Event(), threading.Event()
 
-    def abandon():
-        if section_done.wait(args.other_api_timeout):
+    def abandon(event, seconds: float, what: str):
+        """The line must not be lost to a hang: when `event` is not set within `seconds`, rank 0 prints what it has and
+        every rank leaves (os._exit: a rank stuck in a collective cannot be joined)."""
+        if event.wait(seconds):
             return
         if rank == 0:
-            other["error"] = f"no result after {args.other_api_timeout:.0f} s: the section was abandoned (a hang in a collective?)"
+            other.setdefault("error", f"no result after {seconds:.0f} s: {what} was abandoned (a hang in a collective?)")
             out["other_exchange_api"] = other
             out["wall_clock"] = budget.report()
             if invalid:
@@ -669,7 +671,7 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
     if args.rehearsal and other_api == "cabi" and not hang_hook:
         other["skipped"] = "rehearsal: the library's RCCL communicator needs one rank per GPU"
     elif budget.begin(f"the other exchange API ({other_api}): GHZ+QFT closed form + {max(1, args.ab_steps)} timed steps", optional=True):
-        threading.Thread(target=abandon, daemon=True).start()
+        threading.Thread(target=abandon, args=(section_done, args.other_api_timeout, "the section"), daemon=True).start()
         ab_steps = max(1, args.ab_steps)
         try:
             from quantum_simulations_amd.runner.distributed import DistributedEngine
@@ -703,13 +705,15 @@ def run_multi(args, world: int, rank: int, local_rank: int, k: int) -> tuple[dic
             other["error"] = f"{type(e).__name__}: {e}"[:500]
         section_done.set()
     section_done.set()
-    if rank != 0:
-        engine.close()
-        return None, invalid
-    out["other_exchange_api"] = other
-    out["wall_clock"] = budget.report()
+    # shutting down is a collective too (a barrier, then the process group goes): if a rank left the section above by an
+    # exception the others never saw, it would wait here for ever -- same guard, with the complete line
+    if rank == 0:
+        out["other_exchange_api"] = other
+        out["wall_clock"] = budget.report()
+    threading.Thread(target=abandon, args=(shutdown_done, 90.0, "the shutdown"), daemon=True).start()
     engine.close()
-    return out, invalid
+    shutdown_done.set()
+    return (out if rank == 0 else None), invalid
 
 
 def multi_line(args, world, k, n, n_gates, dt, prof, passes, layout_info, plan_seconds, relayout_measured, fused_ab, single, norm2, xgmi,
