@@ -96,6 +96,14 @@ def _worker(rank, world, port, n, staging_modes, errors, moves=None):
                     (orc.apply_1q if len(g["qubits"]) == 1 else orc.apply_2q)(want2, *g["qubits"], U)
                 err2 = float(np.max(np.abs(eng.state_vector() - want2)))
                 assert err2 < 1e-12, f"{name} repeat staging={staging}/{method}: {err2}"
+                if name == "rand" and n - p >= 5:
+                    # what bench.py measures at N > 1: every re-layout width there and back on the idle shard -- the state
+                    # and the layout are the same afterwards, the records carry bytes and times
+                    before = eng.state_vector()
+                    recs = eng.measure_relayouts(reps=1)
+                    assert [r["m"] for r in recs] == list(range(1, p + 1)) and all(r["wall_ms_pack_exchange_unpack"] > 0 for r in recs)
+                    assert all(r["bytes_sent_per_rank"] == (16 << (n - p)) - ((16 << (n - p)) >> r["m"]) for r in recs)
+                    assert float(np.max(np.abs(eng.state_vector() - before))) == 0.0
                 if method == "tiles" and n - p >= 8:     # (the partition planner really planned this run)
                     assert eng.last_partition_plan["passes"] >= 1 and eng.last_partition_plan["segments"]
                     if mode_no % 2 == 0:                 # ... and with a searched start layout the local slots were placed
