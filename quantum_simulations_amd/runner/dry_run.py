@@ -113,6 +113,25 @@ def main(world: int, rank: int, k: int) -> int:
     docs = []
     rc = run_world(world, rank, k, emit=lambda line: docs.append(json.loads(line)))
     if rank == 0:
+        # A PROJECTION, not a measurement: what the schedules above would take with the pass time measured on one MI355X for
+        # exactly these op lists (tools/shard_compute_probe.py: 6.65 ms per pass at 30 local qubits, profiles/r05b_*) and the
+        # link model of the planner (2^-m of a shard per peer over its own xGMI link at 0.8 x 153 GB/s, nothing hidden
+        # behind compute: an upper bound of the exchange's share).  The first run on a node replaces it.
+        PASS_MS_30 = 6.65
+        for d in docs:
+            shard = 16 << k
+            steps = []
+            for e in range(d["executions"]):
+                passes = max(r["hbm_passes_per_execution"][e] for r in d["per_rank"])
+                steps.append(passes * PASS_MS_30 * 2.0 ** (k - 30))
+            moved = d["per_rank"][0]["bytes_sent"] / max(1, d["executions"])
+            ex = d["per_rank"][0]["exchanges"] / max(1, d["executions"])
+            p_bits = world.bit_length() - 1
+            link_ms = (moved / max(1e-9, ex)) / ((1 << p_bits) - 1) / (0.8 * 153e9) * 1e3 if ex else 0.0   # (full-width re-layouts: all peers at once)
+            step_ms = sum(steps) / len(steps) + ex * link_ms
+            d["projection_model_not_measured"] = {"pass_ms_at_30_local_qubits_measured_on_one_gpu": PASS_MS_30, "compute_ms_per_execution": round(sum(steps) / len(steps), 1),
+                                                  "exchange_ms_per_execution_upper_bound": round(ex * link_ms, 1), "step_ms": round(step_ms, 1),
+                                                  "gate_apps_per_s": round(d["gates"] / (step_ms * 1e-3), 1) if step_ms else None}
         print(json.dumps({"dry_run": True, "n_gpus": world, "local_qubits": k, "n_qubits": k + world.bit_length() - 1,
                           "ok": rc == 0 and all(d["ok"] for d in docs), "exchange": "none (schedule only, gloo control plane)",
                           # the fields a run on devices fills in (bench.py run_multi): measured re-layouts by m, the step with

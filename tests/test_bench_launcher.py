@@ -119,3 +119,9 @@ def test_dry_run_line_names_the_fields_a_device_run_fills_in():
     doc = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     for key in ("relayout_measured", "fused_relayout_ab", "other_exchange_api", "wall_clock"):
         assert key in doc and doc[key] is None
+    # ... and a projection that says of itself that it is one: compute from the measured one-GPU pass time, the exchange
+    # from the planner's link model with nothing hidden behind compute
+    for w in doc["workloads"]:
+        proj = w["projection_model_not_measured"]
+        assert proj["step_ms"] == pytest.approx(proj["compute_ms_per_execution"] + proj["exchange_ms_per_execution_upper_bound"], abs=0.2)
+        assert proj["gate_apps_per_s"] > 0
