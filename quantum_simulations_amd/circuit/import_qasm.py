@@ -8,8 +8,10 @@ The contract's gates are H X Y Z S T RY R(k) G(p) CNOT SWAP CZ CY CR(k) CU.  Wha
     h x y z s t ry cx cz cy swap id                 one gate each
     sdg = Z S, tdg = Z S T                          (diagonal, exact)
     u1 / p (lambda), cu1 / cp (lambda)              lambda = 2 pi m / 2^K, K <= 48: a product of R(k) / CR(k)
-    cu1 / cp (any lambda), crz, crx, cry, cu3, ch   the contract's CU with the 2x2 block as its `U` (exact)
+    cu1 / cp (any lambda), crz, crx, cry, cu3, ch,  the contract's CU with the 2x2 block as its `U` (exact)
+    csx, cu(theta, phi, lambda, gamma)
     ccx, cswap                                      the standard 15-gate Clifford+T decomposition
+    c3x                                             two ccx and five CU with sqrt(X) / its fourth root (exact)
     user `gate` definitions                         expanded in place
     barrier, measure (terminal), creg               dropped
 
@@ -17,7 +19,7 @@ and, exact UP TO A GLOBAL PHASE of the whole state (the contract has RY(theta) f
 other axis is RY between Cliffords: RX(a) = S^dagger RY(a) S, RZ(a) = (S H)^dagger RY(a) (S H) -- runs of 1q gates are fused
 into one 2x2 before they reach the device, so the extra Cliffords cost nothing there):
 
-    rx rz                                           the SU(2) rotation (qelib1's rz(a) = u1(a) = e^{i a / 2} RZ(a))
+    rx rz sx sxdg                                   the SU(2) rotation (qelib1's rz(a) = u1(a) = e^{i a / 2} RZ(a))
     u3(t, p, l) = e^{i (p + l) / 2} RZ(p) RY(t) RZ(l),  u2(p, l) = u3(pi / 2, p, l),  u / U = u3
     u1 / p with an angle that is no dyadic fraction of 2 pi: RZ(lambda) (phase e^{i lambda / 2} dropped)
     rzz(a) = cx; RZ(a) on the target; cx = exp(-i a / 2 Z x Z); rxx, ryy likewise (qelib1's forms carry a phase e^{i a / 2})
@@ -37,11 +39,11 @@ import re
 _SIMPLE = {"h": "H", "x": "X", "y": "Y", "z": "Z", "s": "S", "t": "T", "cx": "CNOT", "cnot": "CNOT",
            "cz": "CZ", "cy": "CY", "swap": "SWAP"}
 _ARITY = {"h": 1, "x": 1, "y": 1, "z": 1, "s": 1, "t": 1, "sdg": 1, "tdg": 1, "id": 1, "ry": 1, "u1": 1, "p": 1,
-          "rx": 1, "rz": 1, "u2": 1, "u3": 1, "u": 1, "U": 1,
+          "rx": 1, "rz": 1, "u2": 1, "u3": 1, "u": 1, "U": 1, "sx": 1, "sxdg": 1, "csx": 2, "cu": 2, "c3x": 4,
           "cx": 2, "cnot": 2, "cz": 2, "cy": 2, "swap": 2, "cu1": 2, "cp": 2, "crz": 2, "crx": 2, "cry": 2, "cu3": 2, "ch": 2,
           "rzz": 2, "rxx": 2, "ryy": 2, "ccx": 3, "cswap": 3}
 _NPARAMS = {"ry": 1, "u1": 1, "p": 1, "cu1": 1, "cp": 1, "rx": 1, "rz": 1, "u2": 2, "u3": 3, "u": 3, "U": 3, "crz": 1, "crx": 1,
-            "cry": 1, "cu3": 3, "rzz": 1, "rxx": 1, "ryy": 1}
+            "cry": 1, "cu3": 3, "rzz": 1, "rxx": 1, "ryy": 1, "cu": 4}
 _MAX_K = 48
 
 
@@ -198,6 +200,13 @@ def _emit_builtin(name: str, params: list[float], q: list[int], out: list) -> No
         rz(q[0], params[0])
     elif name == "rx":
         rx(q[0], params[0])
+    elif name in ("sx", "sxdg"):               # sqrt(X) = e^{i pi / 4} RX(pi / 2), its inverse e^{-i pi / 4} RX(-pi / 2)
+        rx(q[0], math.pi / 2.0 if name == "sx" else -math.pi / 2.0)
+    elif name == "csx":                        # controlled sqrt(X): the phase matters under a control -> CU, exact
+        import numpy as np
+        controlled(np.array([[1 + 1j, 1 - 1j], [1 - 1j, 1 + 1j]], dtype=np.complex128) / 2.0)
+    elif name == "cu":                         # qelib1's cu(theta, phi, lambda, gamma) = controlled e^{i gamma} u3
+        controlled(complex(math.cos(params[3]), math.sin(params[3])) * u3_matrix(*params[:3]))
     elif name in ("u3", "u", "U", "u2"):
         theta, phi, lam = (math.pi / 2.0, params[0], params[1]) if name == "u2" else params
         rz(q[0], lam)
@@ -233,6 +242,19 @@ def _emit_builtin(name: str, params: list[float], q: list[int], out: list) -> No
                        ("tdg", [c]), ("cx", [a, c]), ("t", [b]), ("t", [c]), ("h", [c]), ("cx", [a, b]),
                        ("t", [a]), ("tdg", [b]), ("cx", [a, b])):
             _emit_builtin(nm, [], qs, out)
+    elif name == "c3x":                        # three controls: V = sqrt(X) controlled by c, ccx(a, b -> c), V^dagger, ccx, V by (a, b)
+        import numpy as np                     # (Barenco et al. lemma 7.5 with the last double-controlled V spelled out)
+        a, b, c, t = q
+        V = np.array([[1 + 1j, 1 - 1j], [1 - 1j, 1 + 1j]], dtype=np.complex128) / 2.0
+        sq = np.linalg.eig(V)                  # sqrt(V) through its eigenvectors (H diagonalises it: eigenvalues 1 and i)
+        W = (sq[1] * np.sqrt(sq[0].astype(np.complex128))) @ np.linalg.inv(sq[1])
+        def cu(ctrl, U):
+            out.append({"qubits": [ctrl, t], "gate": "CU", "params": {"U": U, "exponent": 1}})
+        cu(c, V)
+        _emit_builtin("ccx", [], [a, b, c], out)
+        cu(c, V.conj().T)
+        _emit_builtin("ccx", [], [a, b, c], out)
+        cu(b, W), _emit_builtin("cx", [], [a, b], out), cu(b, W.conj().T), _emit_builtin("cx", [], [a, b], out), cu(a, W)
     elif name == "cswap":
         a, b, c = q
         _emit_builtin("cx", [], [c, b], out)
