@@ -221,7 +221,7 @@ def test_qasmbench_inputs_of_the_reference_when_present():
         except ValueError as e:
             assert "unsupported gate" in str(e), (path, e)
             rejected.append(path.parent.name)
-    assert len(ok) >= 40, (ok, rejected)           # (round 5: rotations through RY: 52 of the 59 .qasm files in the tree; the rest need reset / if)
+    assert len(ok) >= 40, (ok, rejected)           # (round 5: rotations through RY: 52 of the 58 .qasm files under QASMBench; the rest need reset / if)
     assert {"ising_n26", "qaoa_n26", "qpe_n26", "vqe_uccsd_n8", "dnn_n16"} <= {name for name, _, _ in ok}
     assert {"qft_n20", "adder_n28", "bv_n30", "grover_n30", "cat_state_n30"} <= {name for name, _, _ in ok}
 
