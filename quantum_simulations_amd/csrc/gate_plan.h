@@ -56,6 +56,11 @@ struct Tuning {
   int tile_group_search = 1; // register groups: try every triple of pending target bits, not only first come
   int tile_had = QSIM_TILE_HAD_DEFAULT;          // uncontrolled c [[1,1],[1,-1]] as add/sub butterflies + one scale per pass (OPC_HAD1 / OPC_SCALE)
   int dense_form = 1;        // (probe build) qsim_apply_fused_k, k = 3, 4: 1 = k_dense_mfma2 (round 5: whole amplitudes per lane), 0 = the round-4 kernels chosen by dense_mfma; QSIM_DENSE_FORM
+  int dense_pf = -1;         // (probe build) k_dense_mfma2's PF (0 none, 1 conditional, 2 unconditional next-group request); QSIM_DENSE_PF
+  int dense_groups = 0;      // (probe build) column groups per wave, k <= 4 (product: 4); QSIM_DENSE_GROUPS
+  int dense_wgs = 0;         // (probe build) resident workgroups per CU the k = 5 grid asks for (product: 4); QSIM_DENSE_WGS
+  int dense_consec = 0;      // (probe build) k <= 4: a wave's column groups are consecutive (else strided through its XCD's region); QSIM_DENSE_CONSEC
+  long long dense_skew = 0;  // (probe build) XCD x starts x * skew column groups into its region; QSIM_DENSE_SKEW
   int dense_mfma = 3;        // qsim_apply_fused_k: bit 0: k = 3, bit 1: k = 4 on the matrix cores (k_dense_mfma; else the vector-ALU k_dense; probe knob QSIM_DENSE_MFMA)
   int debug_skip_gates = 0;  // probe build only: QSIM_DEBUG_SKIP_GATES=1: tile passes move data but apply nothing (WRONG results)
   int tile_order = -1;       // probe build only: QSIM_TILE_ORDER=0/1/2 forces the tile order of k_tile
@@ -86,6 +91,11 @@ struct Tuning {
     if (const char* e = getenv("QSIM_PLAN_SCAN_WINDOW")) plan_scan_window = std::max(1, atoi(e));
     if (const char* e = getenv("QSIM_DENSE_MFMA")) dense_mfma = atoi(e);
     if (const char* e = getenv("QSIM_DENSE_FORM")) dense_form = atoi(e);
+    if (const char* e = getenv("QSIM_DENSE_PF")) dense_pf = atoi(e);
+    if (const char* e = getenv("QSIM_DENSE_GROUPS")) dense_groups = atoi(e);
+    if (const char* e = getenv("QSIM_DENSE_WGS")) dense_wgs = atoi(e);
+    if (const char* e = getenv("QSIM_DENSE_CONSEC")) dense_consec = atoi(e);
+    if (const char* e = getenv("QSIM_DENSE_SKEW")) dense_skew = atoll(e);
     if (const char* e = getenv("QSIM_PLAN_ANCHOR")) plan_anchor = std::max(0, std::min(7, atoi(e)));
     if (const char* e = getenv("QSIM_TILE_MUX")) tile_mux = atoi(e);
     if (const char* e = getenv("QSIM_TILE_COMMUTE_FUSE")) tile_commute_fuse = atoi(e);

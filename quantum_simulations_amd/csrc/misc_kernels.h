@@ -464,6 +464,9 @@ struct DenseMfma2Args {
   u64 col_blocks;           // groups of 16 columns: 2^(k - K - 4)
   int pos[6];               // the block's index bits, ascending
   int to_caller[6];         // pattern bit i (sorted order) -> bit of the caller's pattern
+  int consec_log2;          // a wave takes runs of 2^consec_log2 CONSECUTIVE column groups (its accesses to one pattern then
+                            // cover 2^consec_log2 x 256 contiguous bytes over as many steps), run after run strided through its XCD's region
+  u64 skew;                 // (probe knob) XCD x starts x * skew column groups into its region (wrapping): the eight streams out of step
 };
 template <int K>
 __device__ __forceinline__ double dense_mr_entry(const DenseMfma2Args& a, int t, int s, int lane) {
@@ -476,7 +479,14 @@ __device__ __forceinline__ double dense_mr_entry(const DenseMfma2Args& a, int t,
   const double2 z = a.mat[ro * (1 << K) + ri];
   return co == ci ? z.x : (co ? z.y : -z.y);
 }
-template <int K, bool NT, int THREADS>
+// PF: how the NEXT column group's amplitudes are requested.  1: before this group's products, if there is a next group --
+// the compiler's waits must then cover the case without one, and in the steady state the first MFMA waits for the loads
+// just requested: the overlap is left to the other waves of the SIMD.  Measured best for K <= 5: what bounds them is the
+// memory system's rate for this access shape, and MORE bytes in flight lower it (a true prefetch costs K = 3, 4 3-15 %).
+// 2: requested UNCONDITIONALLY (a wave's last group asks for itself again, unused) after one explicit wait for the first
+// group's loads: no wait in the MFMA chain, the loads land behind it (K = 6, bound by the matrix cores with 2 waves per
+// SIMD: -3 %).  0 (probe build): not ahead at all.  profiles/r05q_dense_knob_scans.txt
+template <int K, bool NT, int THREADS, int PF>
 __global__ __launch_bounds__(THREADS) void k_dense_mfma2(const DenseMfma2Args a) {
   static_assert(K >= 3 && K <= 6, "dense blocks of 3 .. 6 qubits");
   constexpr int TT = 1 << (K - 3);          // 16-row output tiles
@@ -510,10 +520,15 @@ __global__ __launch_bounds__(THREADS) void k_dense_mfma2(const DenseMfma2Args a)
   const bool split = (n_blocks & 7) == 0 && (a.col_blocks & 7) == 0;
   const u64 region = split ? a.col_blocks >> 3 : a.col_blocks;
   const u64 region_base = split ? (bid & 7) * region : 0;
-  const u64 stride = (split ? n_blocks >> 3 : n_blocks) * (THREADS / 64);
-  u64 cb = (split ? bid >> 3 : bid) * (THREADS / 64) + (threadIdx.x >> 6);          // (wave-uniform)
+  const u64 wave_in_region = (split ? bid >> 3 : bid) * (THREADS / 64) + (threadIdx.x >> 6);          // (wave-uniform)
+  const u64 run = 1ull << a.consec_log2;
+  const u64 run_stride = ((split ? n_blocks >> 3 : n_blocks) * (THREADS / 64) - 1) << a.consec_log2;   // from a run's end to the wave's next run
+  u64 cb = wave_in_region << a.consec_log2;
+  const u64 rot = split ? ((bid & 7) * a.skew) % region : 0;
   auto column_ptr = [&](u64 col_block) -> double2* {
-    u64 c = (region_base + col_block) * 16 + (u64)j;
+    u64 cr = col_block + rot;
+    if (cr >= region) cr -= region;
+    u64 c = (region_base + cr) * 16 + (u64)j;
 #pragma unroll
     for (int i = 0; i < K; ++i) { const int p = a.pos[i]; c = ((c >> p) << (p + 1)) | (c & ((1ull << p) - 1)); }
     return a.amp + (c | lane_part);
@@ -523,14 +538,13 @@ __global__ __launch_bounds__(THREADS) void k_dense_mfma2(const DenseMfma2Args a)
   double2 x[MU];
 #pragma unroll
   for (int m = 0; m < MU; ++m) x[m] = ld_amp<NT>(p0 + off[m]);
+  if constexpr (PF == 2) __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0), the other counters left alone (once per wave)
   for (;;) {
-    // the NEXT column group's amplitudes are requested before this one's products start: their latency hides behind the
-    // MFMAs (K = 5, 6: 64 / 256 of them per group)
-    const u64 cb_next = cb + stride;
+    const u64 cb_next = ((cb + 1) & (run - 1)) ? cb + 1 : cb + 1 + run_stride;
     const bool more = cb_next < region;               // (wave-uniform)
     double2* const p1 = more ? column_ptr(cb_next) : p0;
     double2 xn[MU];
-    if (more) {
+    if (PF == 2 || (PF == 1 && more)) {
 #pragma unroll
       for (int m = 0; m < MU; ++m) xn[m] = ld_amp<NT>(p1 + off[m]);
     }
@@ -571,14 +585,26 @@ __global__ __launch_bounds__(THREADS) void k_dense_mfma2(const DenseMfma2Args a)
     if (!more) break;
     cb = cb_next;
     p0 = p1;
+    if constexpr (PF == 0) {
 #pragma unroll
-    for (int m = 0; m < MU; ++m) x[m] = xn[m];
+      for (int m = 0; m < MU; ++m) x[m] = ld_amp<NT>(p0 + off[m]);
+    } else {
+#pragma unroll
+      for (int m = 0; m < MU; ++m) x[m] = xn[m];
+    }
   }
 }
 
+template <int K> constexpr int kDensePf = K == 6 ? 2 : 1;       // the product's choice per K (see PF above)
 template <int K, bool NT, int THREADS>
-static void launch_dense_mfma2(const DenseMfma2Args& d, unsigned grid, hipStream_t stream) {
-  hipLaunchKernelGGL((k_dense_mfma2<K, NT, THREADS>), dim3(grid), dim3(THREADS), 0, stream, d);
+static void launch_dense_mfma2(const DenseMfma2Args& d, unsigned grid, hipStream_t stream, int pf) {
+#ifdef QSIM_PROBES
+  if (pf == 0) { hipLaunchKernelGGL((k_dense_mfma2<K, NT, THREADS, 0>), dim3(grid), dim3(THREADS), 0, stream, d); return; }
+  if (pf == 1) { hipLaunchKernelGGL((k_dense_mfma2<K, NT, THREADS, 1>), dim3(grid), dim3(THREADS), 0, stream, d); return; }
+  if (pf == 2) { hipLaunchKernelGGL((k_dense_mfma2<K, NT, THREADS, 2>), dim3(grid), dim3(THREADS), 0, stream, d); return; }
+#endif
+  (void)pf;
+  hipLaunchKernelGGL((k_dense_mfma2<K, NT, THREADS, kDensePf<K>>), dim3(grid), dim3(THREADS), 0, stream, d);
 }
 
 // Chunks too small for 16 columns per wave (fewer than 2^(K+4) amplitudes): one 64-thread workgroup per block, the block's

@@ -443,26 +443,40 @@ int qsim_apply_fused_k(qsim_chunk* c, int k, const int32_t* qubits, const double
     d.amp = c->amp;
     d.mat = reinterpret_cast<const double2*>(c->scratch);
     d.col_blocks = amps(c) >> (k + 4);
+    d.consec_log2 = 0;
+    d.skew = 0;
     for (int i = 0; i < 6; ++i) {
       d.pos[i] = i < k ? sorted[i] : 0;
       d.to_caller[i] = 0;
       for (int q = 0; q < k; ++q) if (i < k && qubits[q] == sorted[i]) d.to_caller[i] = q;
     }
-    // k <= 4: a wave takes a few column groups (the matrix image costs a few loads per wave); k = 5, 6: resident
-    // workgroups that walk the column groups (the image is built once per workgroup in LDS: 32 / 128 KiB)
+    // k <= 4: a wave takes four CONSECUTIVE column groups (the matrix image costs a few loads per wave; 64 columns = 1 KiB
+    // contiguous per pattern over its four steps: -3 / -5 % against groups strided through the region, the worst
+    // placements -8 / -13 %); k = 5, 6: resident workgroups that walk the column groups (the image is built once per
+    // workgroup in LDS: 32 / 128 KiB) -- for k = 5 TWO per CU, not the four that fit: fewer bytes in flight suit the
+    // memory system better (-9 %; one per CU is as good, three and four are not).  profiles/r05q_dense_knob_scans.txt
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    int pf = -1, groups = 4, wgs_per_cu = 2, consec_log2 = k <= 4 ? 2 : 0;       // (pf: the product's choice per k, kDensePf)
+#ifdef QSIM_PROBES
+    if (tuning().dense_pf >= 0) pf = tuning().dense_pf;
+    if (tuning().dense_groups > 0) groups = tuning().dense_groups;
+    if (tuning().dense_wgs > 0) wgs_per_cu = tuning().dense_wgs;
+    if (tuning().dense_consec > 0) { consec_log2 = 0; while ((2 << consec_log2) <= tuning().dense_consec) ++consec_log2; }
+    d.skew = (u64)tuning().dense_skew;
+#endif
+    d.consec_log2 = consec_log2;
     if (k <= 4) {
-      const u64 waves = (d.col_blocks + 3) / 4;
+      const u64 waves = (d.col_blocks + groups - 1) / groups;
       const unsigned grid = (unsigned)std::min<u64>(((std::max<u64>((waves + 3) / 4, 1) + 7) & ~7ull), 1u << 20);   // (whole octets: one region per XCD)
-      if (k == 3) { if (nt) launch_dense_mfma2<3, true, 256>(d, grid, c->stream); else launch_dense_mfma2<3, false, 256>(d, grid, c->stream); }
-      else        { if (nt) launch_dense_mfma2<4, true, 256>(d, grid, c->stream); else launch_dense_mfma2<4, false, 256>(d, grid, c->stream); }
+      if (k == 3) { if (nt) launch_dense_mfma2<3, true, 256>(d, grid, c->stream, pf); else launch_dense_mfma2<3, false, 256>(d, grid, c->stream, pf); }
+      else        { if (nt) launch_dense_mfma2<4, true, 256>(d, grid, c->stream, pf); else launch_dense_mfma2<4, false, 256>(d, grid, c->stream, pf); }
     } else if (k == 5) {
-      const unsigned grid = (unsigned)std::min<u64>((std::max<u64>((d.col_blocks + 3) / 4, 1) + 7) & ~7ull, (u64)cus * 4);
-      if (nt) launch_dense_mfma2<5, true, 256>(d, grid, c->stream); else launch_dense_mfma2<5, false, 256>(d, grid, c->stream);
+      const unsigned grid = (unsigned)std::min<u64>((std::max<u64>((d.col_blocks + 3) / 4, 1) + 7) & ~7ull, (u64)cus * wgs_per_cu);
+      if (nt) launch_dense_mfma2<5, true, 256>(d, grid, c->stream, pf); else launch_dense_mfma2<5, false, 256>(d, grid, c->stream, pf);
     } else {
       const unsigned grid = (unsigned)std::min<u64>((std::max<u64>((d.col_blocks + 7) / 8, 1) + 7) & ~7ull, (u64)cus);
-      if (nt) launch_dense_mfma2<6, true, 512>(d, grid, c->stream); else launch_dense_mfma2<6, false, 512>(d, grid, c->stream);
+      if (nt) launch_dense_mfma2<6, true, 512>(d, grid, c->stream, pf); else launch_dense_mfma2<6, false, 512>(d, grid, c->stream, pf);
     }
   } else {
     DenseSmallArgs a;

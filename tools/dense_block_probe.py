@@ -2,7 +2,8 @@
 """Rate of the dense k-qubit block kernel (qsim_apply_fused_k) at n qubits: k = 3 .. 6 on low / middle / high / mixed /
 line index bits, median of 5 (HIP events), as a fraction of the 8 TB/s peak of the 32 B x 2^n a launch moves and as
 Tflop/s of its 8 * 2^k flop per amplitude against the 78.6 Tflop/s fp64 matrix peak.  With the probe build and
-QSIM_DENSE_FORM=0 the round-4 kernels run (k <= 4): the A/B partner.
+QSIM_DENSE_FORM=0 the round-4 kernels run (k <= 4): the A/B partner.  DENSE_KS="3,4" restricts the block sizes, DENSE_MORE_SETS=1
+adds fifteen more positions.
     python tools/dense_block_probe.py [n]"""
 import sys
 from pathlib import Path
@@ -23,8 +24,14 @@ sets = [[3, 4, 5], [10, 11, 12], [n - 3, n - 2, n - 1], [5, 14, n - 2], [0, 1, 2
 if not old_form:
     sets += [[3, 4, 5, 6, 7], [10, 11, 12, 13, 14], list(range(n - 5, n)), [5, 14, n - 2, n - 9, 8], [0, 1, 2, 3, 4], [0, 1, 2, 12, n - 1],
              [3, 4, 5, 6, 7, 8], [10, 11, 12, 13, 14, 15], list(range(n - 6, n)), [5, 14, n - 2, n - 9, 8, 11], [0, 1, 2, 3, 4, 5], [0, 1, 2, 12, 20, n - 1]]
+if os.environ.get("DENSE_MORE_SETS"):          # more positions, to see what a launch-shape choice generalises to
+    sets += [[6, 7, 8], [15, 16, 17], [20, 21, 22], [24, 25, 26], [3, 15, 27], [1, 9, 19], [7, 8, 9, 10], [14, 15, 16, 17], [20, 21, 22, 23],
+             [23, 24, 25, 26], [2, 10, 18, 26], [6, 7, 8, 9, 10], [15, 16, 17, 18, 19], [20, 21, 22, 23, 24], [2, 9, 16, 23, n - 1]]
+ks = [int(x) for x in os.environ.get("DENSE_KS", "3,4,5,6").split(",")]
 for qs in sets:
     k = len(qs)
+    if k not in ks:
+        continue
     M = np.linalg.qr(rng.standard_normal((1 << k, 1 << k)) + 1j * rng.standard_normal((1 << k, 1 << k)))[0]
     dev.apply_fused_k(qs, M)
     dev.sync()
