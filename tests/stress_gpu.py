@@ -2,7 +2,7 @@
 """Randomised GPU-vs-oracle stress: fused and per-gate op lists of every gate kind on n = 1..20
 qubits, chunked runs with random chunk sizes, staged/unstaged.  A script, not collected by pytest;
 it lives under tests/ because only test code may use oracle/.
-    python tests/stress_gpu.py [seconds]"""
+    python tests/stress_gpu.py [seconds] [seed]"""
 import sys
 import time
 from pathlib import Path
@@ -16,7 +16,7 @@ from quantum_simulations_amd.runner import single_node  # noqa: E402
 from tests.test_gpu_kernels import _rand_state, _random_ops  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 t0 = time.time()
 cases = 0
 worst = 0.0
